@@ -1,0 +1,162 @@
+/*
+ * mmfe — MI355X (gfx950) signal front-end, C ABI.
+ *
+ * The reference (lixinghe1999/multi_modal) is pure Python and has no FFI of its own: the
+ * boundary it offers for this path is a set of Python call sites that hand a waveform to a
+ * third-party CPU routine.  Each entry point below names the call site(s) it stands behind;
+ * the Python wrappers in multi_modal_amd/ keep those call signatures and bind this library
+ * with ctypes.
+ *
+ *   kind MMFE_KIND_FBANK     torchaudio.compliance.kaldi.fbank(...) called from
+ *                            classification/vggsound/dataset/vggsound.py:45-47, with the
+ *                            pad/cut to 384 frames and the affine normalisation of
+ *                            vggsound.py:48-59 fused in (out_frames / pad_value / out_shift /
+ *                            out_scale).
+ *   kind MMFE_KIND_LOGSPEC   librosa.stft(...) + np.log(|X|^2 + eps) of
+ *                            classification/recognition/dataset/epic_kitchen.py:114-126 and
+ *                            classification/retrieval/dataset/epic_kitchen.py:141-153, with the
+ *                            /255 of classification/recognition/dataset/transform.py:268-285
+ *                            fused in (out_scale).  Also serves the long-utterance log-mel
+ *                            configuration (centre reflect padding, mel, log10, per-clip clamp).
+ *   kind MMFE_KIND_STFT_MAG  np.abs(scipy.signal.stft(x, fs, nperseg, noverlap)[-1]) of
+ *                            classification/har/adbox.py:20.
+ *   kind MMFE_KIND_FRAME     frame_signal(signal, frame_length, hop_length, window) of
+ *                            classification/vggsound/utils/transforms.py:19-61 (identical copies
+ *                            under recognition/ and retrieval/).
+ *
+ * Conventions
+ *   - Every function returns 0 on success and a negative MMFE_E* code on failure; the message is
+ *     available from mmfe_last_error() (thread-local).  Nothing throws across the ABI, nothing
+ *     calls exit().
+ *   - All data pointers passed to mmfe_run* are DEVICE pointers owned by the caller (e.g.
+ *     tensor.data_ptr()).  The library allocates only plan-lifetime constant tables.
+ *   - mmfe_run* is asynchronous on the given HIP stream (NULL = the default stream); it never
+ *     synchronises and never allocates.
+ *   - There is no CPU path: creating a plan without a usable gfx950 device fails.
+ */
+#ifndef MMFE_H
+#define MMFE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMFE_ABI_VERSION 1
+
+/* error codes */
+#define MMFE_OK            0
+#define MMFE_EINVAL       -1   /* bad argument / unsupported parameter combination */
+#define MMFE_ENODEVICE    -2   /* no usable HIP device */
+#define MMFE_EHIP         -3   /* a HIP runtime call failed */
+#define MMFE_ENOMEM       -4
+
+/* mmfe_spec.kind */
+#define MMFE_KIND_FBANK     1
+#define MMFE_KIND_LOGSPEC   2
+#define MMFE_KIND_STFT_MAG  3
+#define MMFE_KIND_FRAME     4
+
+/* mmfe_spec.pad_mode: how samples outside [0, n) are read */
+#define MMFE_PAD_NONE     0    /* never read outside (snip-edges framing) */
+#define MMFE_PAD_ZERO     1
+#define MMFE_PAD_REFLECT  2
+
+/* mmfe_spec.frames_mode: number of frames for an n-sample row */
+#define MMFE_FRAMES_SNIP    0  /* n < win_len ? 0 : 1 + (n - win_len) / hop          (kaldi snip_edges) */
+#define MMFE_FRAMES_CENTER  1  /* 1 + n / hop, frame t centred on sample t*hop        (librosa center=True) */
+#define MMFE_FRAMES_SCIPY   2  /* 1 + ceil(n / hop), zero-extended by win_len/2       (scipy boundary='zeros', padded) */
+#define MMFE_FRAMES_CEIL    3  /* n <= win_len ? 1 : 1 + ceil((n - win_len) / hop), zero pad split floor/ceil (frame_signal) */
+
+/* mmfe_spec.log_kind */
+#define MMFE_LOG_NONE       0
+#define MMFE_LOG_LN_MAX     1  /* ln(max(x, log_floor))      kaldi */
+#define MMFE_LOG_LN_ADD     2  /* ln(x + log_floor)          EPIC  */
+#define MMFE_LOG_LOG10_MAX  3  /* log10(max(x, log_floor))   long-utterance log-mel */
+
+/* mmfe_spec.layout */
+#define MMFE_LAYOUT_TIME_MAJOR  0  /* out[row][frame][feature] */
+#define MMFE_LAYOUT_FEAT_MAJOR  1  /* out[row][feature][frame] */
+
+typedef struct mmfe_spec {
+    int32_t struct_size;   /* = sizeof(mmfe_spec) */
+    int32_t kind;          /* MMFE_KIND_* */
+    int32_t n_fft;         /* DFT length (any value >= 2 for LOGSPEC; power of two for FBANK / STFT_MAG) */
+    int32_t win_len;       /* number of window taps (<= n_fft); FRAME: frame_length */
+    int32_t win_off;       /* position of tap 0 inside the n_fft-long DFT input (zeros elsewhere) */
+    int32_t hop;
+    int32_t pad_mode;      /* MMFE_PAD_* */
+    int32_t frames_mode;   /* MMFE_FRAMES_* */
+    int32_t n_mel;         /* 0 = no mel projection, features are the n_fft/2+1 DFT bins */
+    int32_t remove_dc;     /* subtract the per-frame mean before pre-emphasis (kaldi) */
+    float   preemph;       /* 0 = off; y[j] = x[j] - preemph * x[max(j-1,0)] */
+    int32_t power;         /* 1 = |X|, 2 = |X|^2 */
+    float   spec_scale;    /* multiplies X before |.| (scipy 'spectrum' scaling = 1/sum(window)); 1 = off */
+    int32_t log_kind;      /* MMFE_LOG_* */
+    float   log_floor;
+    float   out_shift;     /* result = (value + out_shift) * out_scale */
+    float   out_scale;
+    int32_t out_frames;    /* 0 = natural frame count; else rows are cut / padded to this many frames */
+    float   pad_value;     /* value (before shift/scale) of padded frames */
+    int32_t drop_last;     /* drop the last natural frame (long-utterance log-mel) */
+    float   clamp_below_max; /* > 0: per-row clamp to (row max - clamp_below_max) before shift/scale */
+    int32_t layout;        /* MMFE_LAYOUT_* */
+    int32_t window_f64;    /* 1: the `window` argument of mmfe_plan_create points to doubles (librosa / scipy build
+                              their windows in float64 and multiply in float64); 0: floats */
+} mmfe_spec;
+
+typedef struct mmfe_plan mmfe_plan;
+
+/* Library / ABI version (MMFE_ABI_VERSION of the build). */
+int mmfe_abi_version(void);
+
+/* Last error message of the calling thread ("" if none). */
+const char* mmfe_last_error(void);
+
+/* Number of usable devices (0 when there is none; never fails). */
+int mmfe_device_count(void);
+
+/* Output shape for rows of n_samples samples: number of frames and features per frame.
+ * Pure host arithmetic, no device needed.
+ * Stands for the shape rules of kaldi snip-edges framing, librosa centred framing,
+ * scipy.signal.stft and frame_signal (transforms.py:32-37). */
+int mmfe_spec_out_shape(const mmfe_spec* spec, int64_t n_samples, int64_t* n_frames, int64_t* n_feat);
+
+/* Build a plan: validates the spec, uploads the constant tables to `device`.
+ *   window        host, win_len floats (doubles when spec->window_f64), the values exactly as the
+ *                 reference library builds them
+ *   band_start    host, n_mel ints: first DFT bin of each mel filter          (NULL when n_mel == 0)
+ *   band_len      host, n_mel ints: number of consecutive bins of each filter (0 allowed)
+ *   band_weights  host, sum(band_len) floats, filter after filter
+ * Replaces the per-call table construction inside kaldi.fbank / librosa.stft / scipy.signal.stft. */
+int mmfe_plan_create(const mmfe_spec* spec, const void* window,
+                     const int32_t* band_start, const int32_t* band_len, const float* band_weights,
+                     int device, mmfe_plan** out_plan);
+
+int mmfe_plan_destroy(mmfe_plan* plan);
+
+/* Run the transform on a batch.
+ *   in         device, n_rows rows of n_samples floats, row r at in + r * in_stride
+ *   out        device, contiguous (n_rows, frames, feat) or (n_rows, feat, frames) per spec.layout,
+ *              frames/feat as reported by mmfe_spec_out_shape (after out_frames / drop_last)
+ *   hip_stream hipStream_t or NULL
+ * Stands where the reference calls kaldi.fbank (vggsound.py:45), librosa.stft + log
+ * (epic_kitchen.py:119-125), scipy.signal.stft + abs (adbox.py:20) or frame_signal. */
+int mmfe_run(const mmfe_plan* plan, const float* in, int64_t in_stride, int64_t n_rows, int64_t n_samples,
+             float* out, void* hip_stream);
+
+/* Same transform, but row r is the slice [offsets[r], offsets[r] + n_samples) of recording
+ * rec_index[r] in a packed device buffer (recording i starts at recs + rec_start[i]).  Stands for
+ * the slicing in EPICKitchen._extract_sound_feature (epic_kitchen.py:128-154) feeding _log_specgram. */
+int mmfe_run_slices(const mmfe_plan* plan, const float* recs, const int64_t* rec_start, const int32_t* rec_index,
+                    const int64_t* offsets, int64_t n_rows, int64_t n_samples, float* out, void* hip_stream);
+
+/* Sum and sum of squares (float64) of n device floats, accumulated into sums[0], sums[1] (device,
+ * caller zeroes them).  Stands for the two DataLoader passes of cal_norm (vggsound.py:85-107). */
+int mmfe_feature_sums(const float* x, int64_t n, double* sums, int device, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMFE_H */

@@ -1,0 +1,342 @@
+// Log-(mel-)spectrogram for ANY DFT length on gfx950: direct DFT with an exact-index twiddle table.
+//
+// Stands behind  librosa.stft(audio, n_fft=511, hop_length=120, win_length=240, window='hann',
+// pad_mode='constant')  followed by  np.log(|X|^2 + eps)  as the reference calls them
+// (classification/recognition/dataset/epic_kitchen.py:119-125, same code at
+// classification/retrieval/dataset/epic_kitchen.py:146-152), with the /255 of
+// classification/recognition/dataset/transform.py:285 folded into out_scale.  n_fft = 511 = 7*73 has
+// no radix-2 structure and only win_len = 240 of its 511 inputs are non-zero, so the transform is
+// evaluated as  X[k] = sum_j u[j] * W[(win_off + j) * k mod n_fft]  with the twiddle index kept as
+// an exact integer (no angle accumulation).  The same kernel serves centred log-mel with reflect
+// padding (n_fft = 400) and snip-edges fbank for window sizes the radix kernels do not cover.
+//
+// Mapping: a block owns FR consecutive frames of one row.  The windowed frames are staged once in
+// LDS as u[tap][frame]; thread k accumulates bin k of all FR frames in registers (one 8-byte
+// twiddle read and FR/4 broadcast 16-byte reads per tap), then the block applies |.|^2, the banded
+// mel projection (from LDS), the log and the affine map and stores in the requested layout.
+#include "mmfe_internal.h"
+#include "fft_regs.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace mmfe {
+
+namespace {
+
+constexpr int FR = 16;           // frames per block
+constexpr int kThreads = 256;
+
+struct DftArgs {
+    RowSource src;
+    float* out;
+    float* rowmax;         // per-row running max as ordered int (clamp_below_max), or nullptr
+    int n_rows;
+    int n_samples;
+    int frames_valid;      // frames computed per row
+    int out_frames;        // frames per row in the output tensor
+    int n_fft, win_len, win_off, hop;
+    int centre_shift;      // frame t, tap j reads sample t*hop + j + centre_shift
+    int pad_mode;
+    int n_bins, n_mel, n_feat;
+    int remove_dc;
+    float preemph;
+    int power;
+    float spec_scale;
+    int log_kind;
+    float log_floor;
+    float log_of_floor;
+    float out_shift, out_scale;
+    int layout;
+    const double* window;      // win_len doubles
+    const double2* tw;         // n_fft entries exp(-2 pi i n / n_fft), float64
+    const int32_t* band_start;
+    const int32_t* band_len;
+    const int32_t* band_off;
+    const float* band_w;
+};
+
+__device__ __forceinline__ float fetch_sample(const float* row, int i, int n, int pad_mode) {
+    if (i >= 0 && i < n) return row[i];
+    if (pad_mode == MMFE_PAD_REFLECT) {
+        if (n == 1) return row[0];
+        const int period = 2 * (n - 1);
+        int m = i % period;
+        if (m < 0) m += period;
+        return row[m < n ? m : period - m];
+    }
+    return 0.f;
+}
+
+// `log_of_floor` is log(floor) rounded on the host, so floored cells carry the same value the
+// reference's CPU libm produces (device logf is within 1 ulp, not correctly rounded).
+__device__ __forceinline__ float dft_log(float x, int kind, float floor_, float log_of_floor) {
+    switch (kind) {
+        case MMFE_LOG_LN_MAX: return x <= floor_ ? log_of_floor : logf(x);
+        case MMFE_LOG_LN_ADD: return logf(x + floor_);
+        case MMFE_LOG_LOG10_MAX: return x <= floor_ ? log_of_floor : log10f(x);
+        default: return x;
+    }
+}
+
+// monotone map float -> int so that atomicMax on ints orders floats
+__device__ __forceinline__ int float_to_ordered(float f) {
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+
+__global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double2* s_tw = reinterpret_cast<double2*>(smem);                     // n_fft
+    double* s_u = reinterpret_cast<double*>(s_tw + p.n_fft);              // win_len * FR, [tap][frame], float64
+    float* s_p = reinterpret_cast<float*>(s_u + p.win_len * FR);                                     // FR * (n_bins + 1), [frame][bin]
+    const int pstride = p.n_bins + 1;
+
+    for (int i = threadIdx.x; i < p.n_fft; i += kThreads) s_tw[i] = p.tw[i];
+
+    const int blocks_per_row = (p.frames_valid + FR - 1) / FR;
+    const int64_t n_work = (int64_t)p.n_rows * blocks_per_row;
+
+    for (int64_t work = blockIdx.x; work < n_work; work += gridDim.x) {
+        const int row = (int)(work / blocks_per_row);
+        const int t0 = (int)(work - (int64_t)row * blocks_per_row) * FR;
+        const int nfr = min(FR, p.frames_valid - t0);
+        const float* rp = row_ptr(p.src, row);
+
+        __syncthreads();   // previous work item is done with s_u / s_p (and s_tw is loaded)
+        // ---- stage windowed frames: u[j][f] ---------------------------------------------------
+        for (int i = threadIdx.x; i < p.win_len * FR; i += kThreads) {
+            const int f = i / p.win_len;          // consecutive threads walk consecutive taps: coalesced reads
+            const int j = i - f * p.win_len;
+            double v = 0.0;
+            if (f < nfr) {
+                const int base = (t0 + f) * p.hop + p.centre_shift;
+                float x = fetch_sample(rp, base + j, p.n_samples, p.pad_mode);
+                if (p.preemph != 0.f && !p.remove_dc) {
+                    const float prev = fetch_sample(rp, base + (j > 0 ? j - 1 : 0), p.n_samples, p.pad_mode);
+                    x = x - p.preemph * prev;
+                }
+                v = x;
+                if (!p.remove_dc) v *= p.window[j];      // float64 window x float32 sample, rounded in float64
+            }
+            s_u[j * FR + f] = v;
+        }
+        __syncthreads();
+        if (p.remove_dc) {
+            // kaldi order: subtract the frame mean, pre-emphasise the centred samples, then window.
+            // One thread per frame walks its taps (rarely used path: only for window sizes the radix
+            // kernels do not cover).
+            if (threadIdx.x < FR) {
+                const int f = threadIdx.x;
+                float s = 0.f;
+                for (int j = 0; j < p.win_len; ++j) s += (float)s_u[j * FR + f];
+                const float mean = s / (float)p.win_len;
+                float prev = (float)s_u[f] - mean;
+                for (int j = 0; j < p.win_len; ++j) {
+                    const float g = (float)s_u[j * FR + f] - mean;
+                    s_u[j * FR + f] = (double)((g - p.preemph * prev) * (float)p.window[j]);
+                    prev = g;
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- direct DFT: thread k owns bin k (and k + 256, ...) for all FR frames.  Products and sums
+        //      are float64, the arithmetic type of the librosa path (fp64 window x fp32 frame, fp64
+        //      FFT, result rounded to complex64); gfx950 issues v_fma_f64 at the fp32 FMA rate. -------
+        for (int k = threadIdx.x; k < p.n_bins; k += kThreads) {
+            double re[FR], im[FR];
+#pragma unroll
+            for (int f = 0; f < FR; ++f) { re[f] = 0.0; im[f] = 0.0; }
+            int idx = (int)(((int64_t)p.win_off * k) % p.n_fft);
+            for (int j = 0; j < p.win_len; ++j) {
+                const double2 w = s_tw[idx];
+                idx += k;
+                if (idx >= p.n_fft) idx -= p.n_fft;
+                const double2* up = reinterpret_cast<const double2*>(s_u + j * FR);
+#pragma unroll
+                for (int q = 0; q < FR / 2; ++q) {
+                    const double2 u = up[q];
+                    re[2 * q + 0] = fma(u.x, w.x, re[2 * q + 0]); im[2 * q + 0] = fma(u.x, w.y, im[2 * q + 0]);
+                    re[2 * q + 1] = fma(u.y, w.x, re[2 * q + 1]); im[2 * q + 1] = fma(u.y, w.y, im[2 * q + 1]);
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < FR; ++f) {
+                // complex64 rounding of the spectrum, then fp32 |.|^2 like the reference's numpy expression
+                const float xr = (float)(re[f] * (double)p.spec_scale), xi = (float)(im[f] * (double)p.spec_scale);
+                float v = xr * xr + xi * xi;
+                if (p.power == 1) v = sqrtf(v);
+                s_p[f * pstride + k] = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- mel (optional), log, affine, store ------------------------------------------------
+        const int nfeat = p.n_feat;
+        const int total = nfr * nfeat;
+        float local_max = -INFINITY;
+        for (int i = threadIdx.x; i < FR * nfeat; i += kThreads) {
+            int f, m;
+            if (p.layout == MMFE_LAYOUT_FEAT_MAJOR) { m = i / FR; f = i - m * FR; }    // frames fastest: matches out[row][m][t]
+            else { f = i / nfeat; m = i - f * nfeat; }                                  // features fastest: matches out[row][t][m]
+            if (f >= nfr) continue;
+            float v;
+            if (p.n_mel > 0) {
+                const int st = p.band_start[m], len = p.band_len[m];
+                const float* w = p.band_w + p.band_off[m];
+                const float* sp = s_p + f * pstride + st;
+                v = 0.f;
+                for (int q = 0; q < len; ++q) v = fmaf(w[q], sp[q], v);
+            } else {
+                v = s_p[f * pstride + m];
+            }
+            v = dft_log(v, p.log_kind, p.log_floor, p.log_of_floor);
+            int64_t o;
+            if (p.layout == MMFE_LAYOUT_FEAT_MAJOR) o = ((int64_t)row * nfeat + m) * p.out_frames + (t0 + f);
+            else o = ((int64_t)row * p.out_frames + (t0 + f)) * nfeat + m;
+            if (p.rowmax != nullptr) {
+                p.out[o] = v;                 // clamp + affine happen in the second pass
+                local_max = fmaxf(local_max, v);
+            } else {
+                p.out[o] = (v + p.out_shift) * p.out_scale;
+            }
+        }
+        (void)total;
+        if (p.rowmax != nullptr) {
+            // wave max, then one atomic per wave
+            for (int off = 32; off > 0; off >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, off));
+            if ((threadIdx.x & 63) == 0 && local_max > -INFINITY)
+                atomicMax(reinterpret_cast<int*>(p.rowmax) + row, float_to_ordered(local_max));
+        }
+    }
+}
+
+__global__ void rowmax_init_kernel(int* rowmax, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rowmax[i] = float_to_ordered(-INFINITY);
+}
+
+// second pass of clamp_below_max: x = max(x, rowmax - c), then affine
+__global__ void clamp_affine_kernel(float* out, const int* rowmax, int64_t per_row, int64_t total, float c, float shift,
+                                    float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / per_row);
+        const int oi = rowmax[row];
+        const float mx = __int_as_float(oi >= 0 ? oi : oi ^ 0x7fffffff);
+        out[i] = (fmaxf(out[i], mx - c) + shift) * scale;
+    }
+}
+
+}  // namespace
+
+int dftgen_prepare(Plan& plan) {
+    const mmfe_spec& s = plan.spec;
+    if (s.n_fft < 2 || s.n_fft > 4096 || s.win_len < 1 || s.win_off < 0 || s.win_off + s.win_len > s.n_fft) {
+        set_error("dftgen: needs 2 <= n_fft <= 4096 and the window inside the DFT input");
+        return MMFE_EINVAL;
+    }
+    std::vector<double> tw(2 * (size_t)s.n_fft);
+    const double pi = 3.14159265358979323846;
+    for (int n = 0; n < s.n_fft; ++n) {
+        tw[2 * n] = std::cos(2.0 * pi * n / s.n_fft);
+        tw[2 * n + 1] = -std::sin(2.0 * pi * n / s.n_fft);
+    }
+    int rc;
+    if ((rc = upload(&plan.d_tw64, tw))) return rc;
+    if ((rc = upload(&plan.d_window64, plan.window64))) return rc;
+    if (s.n_mel > 0) {
+        std::vector<int32_t> off(s.n_mel, 0);
+        int acc = 0;
+        for (int m = 0; m < s.n_mel; ++m) {
+            off[m] = acc;
+            acc += plan.band_len[m];
+            if (plan.band_len[m] > 0 && (plan.band_start[m] < 0 || plan.band_start[m] + plan.band_len[m] > plan.n_bins)) {
+                set_error("dftgen: mel band %d leaves the spectrum", m);
+                return MMFE_EINVAL;
+            }
+        }
+        std::vector<int32_t> st = plan.band_start;
+        for (int m = 0; m < s.n_mel; ++m) if (plan.band_len[m] == 0) st[m] = 0;
+        if ((rc = upload(&plan.d_band_start, st))) return rc;
+        if ((rc = upload(&plan.d_band_len, plan.band_len))) return rc;
+        if ((rc = upload(&plan.d_band_off, off))) return rc;
+        std::vector<float> w = plan.band_weights;
+        if (w.empty()) w.push_back(0.f);
+        if ((rc = upload(&plan.d_band_w, w))) return rc;
+    }
+    return MMFE_OK;
+}
+
+int dftgen_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames_natural,
+                  int64_t out_frames, float* out, hipStream_t stream) {
+    const mmfe_spec& s = plan.spec;
+    const int64_t frames_valid = std::min(n_frames_natural, out_frames);
+    if (n_rows <= 0 || frames_valid <= 0) return MMFE_OK;
+    if (n_rows >= (int64_t)1 << 31 || n_samples >= (int64_t)1 << 30) {
+        set_error("dftgen: batch too large for one launch");
+        return MMFE_EINVAL;
+    }
+    DftArgs a{};
+    a.src = src;
+    a.out = out;
+    a.rowmax = nullptr;
+    a.n_rows = (int)n_rows;
+    a.n_samples = (int)n_samples;
+    a.frames_valid = (int)frames_valid;
+    a.out_frames = (int)out_frames;
+    a.n_fft = s.n_fft; a.win_len = s.win_len; a.win_off = s.win_off; a.hop = s.hop;
+    a.centre_shift = (s.frames_mode == MMFE_FRAMES_CENTER) ? s.win_off - s.n_fft / 2 : 0;
+    a.pad_mode = s.pad_mode;
+    a.n_bins = plan.n_bins; a.n_mel = s.n_mel; a.n_feat = s.n_mel > 0 ? s.n_mel : plan.n_bins;
+    a.remove_dc = s.remove_dc; a.preemph = s.preemph; a.power = s.power; a.spec_scale = s.spec_scale;
+    a.log_kind = s.log_kind; a.log_floor = s.log_floor;
+    a.log_of_floor = s.log_kind == MMFE_LOG_LOG10_MAX ? (float)std::log10((double)s.log_floor) : (float)std::log((double)s.log_floor);
+    a.out_shift = s.out_shift; a.out_scale = s.out_scale;
+    a.layout = s.layout;
+    a.window = plan.d_window64;
+    a.tw = reinterpret_cast<const double2*>(plan.d_tw64);
+    a.band_start = plan.d_band_start; a.band_len = plan.d_band_len; a.band_off = plan.d_band_off; a.band_w = plan.d_band_w;
+
+    const bool clamp = s.clamp_below_max > 0.f;
+    if (clamp) {
+        if (n_rows > plan.rowmax_capacity) {
+            set_error("dftgen: clamp_below_max supports at most %lld rows per call", (long long)plan.rowmax_capacity);
+            return MMFE_EINVAL;
+        }
+        a.rowmax = plan.d_rowmax;
+        hipLaunchKernelGGL(rowmax_init_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream,
+                           reinterpret_cast<int*>(plan.d_rowmax), (int)n_rows);
+        MMFE_HIP_CHECK(hipGetLastError());
+    }
+    const size_t lds = (size_t)s.n_fft * 16 + (size_t)s.win_len * FR * 8 + (size_t)FR * (plan.n_bins + 1) * 4;
+    if (lds > 160 * 1024) {
+        set_error("dftgen: n_fft %d / win_len %d need %zu bytes of LDS", s.n_fft, s.win_len, lds);
+        return MMFE_EINVAL;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        MMFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dftgen_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    int dev = 0, cus = 256;
+    MMFE_HIP_CHECK(hipGetDevice(&dev));
+    MMFE_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int64_t work = n_rows * ((frames_valid + FR - 1) / FR);
+    const int grid = (int)std::min<int64_t>(work, (int64_t)cus * 8);
+    hipLaunchKernelGGL(dftgen_kernel, dim3(grid), dim3(kThreads), lds, stream, a);
+    MMFE_HIP_CHECK(hipGetLastError());
+    if (clamp) {
+        const int64_t per_row = out_frames * a.n_feat;
+        const int64_t total = per_row * n_rows;
+        const int g2 = (int)std::min<int64_t>((total + 255) / 256, (int64_t)cus * 16);
+        hipLaunchKernelGGL(clamp_affine_kernel, dim3(g2), dim3(256), 0, stream, out,
+                           reinterpret_cast<const int*>(plan.d_rowmax), per_row, total, s.clamp_below_max, s.out_shift,
+                           s.out_scale);
+        MMFE_HIP_CHECK(hipGetLastError());
+    }
+    return MMFE_OK;
+}
+
+}  // namespace mmfe

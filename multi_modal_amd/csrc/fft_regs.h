@@ -1,0 +1,94 @@
+// Register-resident radix building blocks for gfx950 (wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mmfe {
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// 4-point forward DFT in place: (a0,a1,a2,a3) -> (X0,X1,X2,X3), W4 = -i.
+__device__ __forceinline__ void dft4(float2& a0, float2& a1, float2& a2, float2& a3) {
+    const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = csub(a1, a3);
+    a0 = cadd(t0, t2);
+    a2 = csub(t0, t2);
+    a1 = make_float2(t1.x + t3.y, t1.y - t3.x);
+    a3 = make_float2(t1.x - t3.y, t1.y + t3.x);
+}
+
+// x *= W16^M  (W16 = exp(-2*pi*i/16)), M a compile-time constant in [0, 9].
+template <int M>
+__device__ __forceinline__ float2 mul_w16(float2 v) {
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
+    if constexpr (M == 0) return v;
+    else if constexpr (M == 1) return make_float2(v.x * C1 + v.y * S1, v.y * C1 - v.x * S1);
+    else if constexpr (M == 2) return make_float2((v.x + v.y) * H, (v.y - v.x) * H);
+    else if constexpr (M == 3) return make_float2(v.x * S1 + v.y * C1, v.y * S1 - v.x * C1);
+    else if constexpr (M == 4) return make_float2(v.y, -v.x);
+    else if constexpr (M == 6) return make_float2((v.y - v.x) * H, -(v.x + v.y) * H);
+    else {
+        static_assert(M == 9, "unsupported W16 power");
+        return make_float2(-v.x * C1 - v.y * S1, v.x * S1 - v.y * C1);   // W16^9 = (-C1, +S1)
+    }
+}
+
+// 16-point forward DFT in place.  Input x[n] in natural order; output X[k] is left at
+// x[fft16_pos(k)] (digit-reversed positions), so callers index with fft16_pos() at compile time.
+__host__ __device__ constexpr int fft16_pos(int k) { return 4 * (k & 3) + (k >> 2); }
+
+__device__ __forceinline__ void fft16(float2 (&x)[16]) {
+    // radix-4 over n1 for each n2: x[4*n1 + n2] -> A[n2][k1] stored at x[4*k1 + n2]
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) dft4(x[n2], x[4 + n2], x[8 + n2], x[12 + n2]);
+    // twiddles W16^(n2*k1)
+    x[4 * 1 + 1] = mul_w16<1>(x[4 * 1 + 1]);
+    x[4 * 1 + 2] = mul_w16<2>(x[4 * 1 + 2]);
+    x[4 * 1 + 3] = mul_w16<3>(x[4 * 1 + 3]);
+    x[4 * 2 + 1] = mul_w16<2>(x[4 * 2 + 1]);
+    x[4 * 2 + 2] = mul_w16<4>(x[4 * 2 + 2]);
+    x[4 * 2 + 3] = mul_w16<6>(x[4 * 2 + 3]);
+    x[4 * 3 + 1] = mul_w16<3>(x[4 * 3 + 1]);
+    x[4 * 3 + 2] = mul_w16<6>(x[4 * 3 + 2]);
+    x[4 * 3 + 3] = mul_w16<9>(x[4 * 3 + 3]);
+    // radix-4 over n2 for each k1: x[4*k1 + k2] = X[k1 + 4*k2]
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) dft4(x[4 * k1], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);
+}
+
+// ---- DPP helpers (16-lane rows) ----------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {   // lanes without a source read 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_upd(float old, float v) {   // lanes without a source keep `old`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;        // quad_perm [1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;        // quad_perm [2,3,0,1]
+constexpr int DPP_ROW_SHR1 = 0x111;        // lane i <- lane i-1 of the same 16-lane row
+constexpr int DPP_ROW_ROR1 = 0x121;        // lane i <- lane (i-1) mod 16
+constexpr int DPP_ROW_MIRROR = 0x140;      // lane i <- lane 15-i
+constexpr int DPP_ROW_HALF_MIRROR = 0x141; // lane i <- lane 7-i within each half row
+
+// Sum over each 16-lane row; every lane of the row ends with the same total.
+__device__ __forceinline__ float row16_sum(float s) {
+    s += dpp_mov<DPP_QUAD_XOR1>(s);
+    s += dpp_mov<DPP_QUAD_XOR2>(s);
+    s += dpp_mov<DPP_ROW_HALF_MIRROR>(s);
+    s += dpp_mov<DPP_ROW_MIRROR>(s);
+    return s;
+}
+
+// Orders LDS traffic between the lanes of one wave (no instruction is emitted for it beyond what
+// the memory model requires: a wave's DS operations already execute in program order).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+}  // namespace mmfe

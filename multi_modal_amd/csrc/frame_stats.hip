@@ -1,0 +1,144 @@
+// Layout-only helpers of the front-end: framing with a window (no transform), padded-frame fill,
+// and the feature statistics reduction.
+//
+//   frame_kernel       frame_signal(signal, frame_length, hop_length, window)
+//                      (classification/vggsound/utils/transforms.py:19-61): centre zero padding split
+//                      floor/ceil, strided gather, multiply by the window.
+//   fill_kernel        the ZeroPad2d rows appended when a clip has fewer than out_frames frames
+//                      (classification/vggsound/dataset/vggsound.py:52-54), already normalised.
+//   sums_kernel        sum and sum of squares of a feature tensor, the arithmetic of the two passes of
+//                      cal_norm (classification/vggsound/dataset/vggsound.py:85-107), in float64.
+#include "mmfe_internal.h"
+
+#include <algorithm>
+
+namespace mmfe {
+
+namespace {
+
+struct FrameArgs {
+    RowSource src;
+    float* out;
+    const float* window;
+    int64_t n_rows;
+    int n_samples, n_frames, frame_len, hop, left_pad;
+};
+
+__global__ void __launch_bounds__(256) frame_kernel(const FrameArgs p) {
+    const int64_t per_row = (int64_t)p.n_frames * p.frame_len;
+    const int64_t total = p.n_rows * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / per_row;
+        const int rem = (int)(i - row * per_row);
+        const int f = rem / p.frame_len;
+        const int j = rem - f * p.frame_len;
+        const int idx = f * p.hop + j - p.left_pad;
+        float v = 0.f;
+        if (idx >= 0 && idx < p.n_samples) v = row_ptr(p.src, row)[idx];
+        p.out[i] = v * p.window[j];
+    }
+}
+
+__global__ void __launch_bounds__(256) fill_kernel(float* out, int64_t n_rows, int64_t out_frames, int64_t first_pad,
+                                                   int64_t n_feat, int layout, float value) {
+    const int64_t pad_frames = out_frames - first_pad;
+    const int64_t per_row = pad_frames * n_feat;
+    const int64_t total = n_rows * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / per_row;
+        const int64_t rem = i - row * per_row;
+        int64_t o;
+        if (layout == MMFE_LAYOUT_TIME_MAJOR) {
+            o = (row * out_frames + first_pad) * n_feat + rem;          // padded frames are one contiguous tail
+        } else {
+            const int64_t m = rem / pad_frames, t = rem - m * pad_frames;
+            o = (row * n_feat + m) * out_frames + first_pad + t;
+        }
+        out[o] = value;
+    }
+}
+
+__global__ void __launch_bounds__(256) sums_kernel(const float* x, int64_t n, double* sums) {
+    double s = 0.0, q = 0.0;
+    const int64_t n4 = n / 4;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = x4[i];
+        s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+        q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) {
+        const float v = x[n4 * 4 + threadIdx.x];
+        s += v;
+        q += (double)v * v;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off);
+        q += __shfl_xor(q, off);
+    }
+    __shared__ double sh[2][4];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][wave] = s; sh[1][wave] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[0], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
+        atomicAdd(&sums[1], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
+    }
+}
+
+int grid_for(int64_t total, int per_block) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess) return 1024;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    return (int)std::max<int64_t>(1, std::min<int64_t>((total + per_block - 1) / per_block, (int64_t)cus * 8));
+}
+
+}  // namespace
+
+int frame_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames,
+                 float* out, hipStream_t stream) {
+    const mmfe_spec& s = plan.spec;
+    if (n_rows <= 0 || n_frames <= 0) return MMFE_OK;
+    if (n_samples >= (int64_t)1 << 30 || n_frames * (int64_t)s.win_len >= (int64_t)1 << 31) {
+        set_error("frame: row too long for one launch");
+        return MMFE_EINVAL;
+    }
+    FrameArgs a{};
+    a.src = src;
+    a.out = out;
+    a.window = plan.d_window;
+    a.n_rows = n_rows;
+    a.n_samples = (int)n_samples;
+    a.n_frames = (int)n_frames;
+    a.frame_len = s.win_len;
+    a.hop = s.hop;
+    const int64_t pad_len = (n_frames - 1) * s.hop + s.win_len;
+    a.left_pad = pad_len > n_samples ? (int)((pad_len - n_samples) / 2) : 0;
+    const int64_t total = n_rows * n_frames * s.win_len;
+    hipLaunchKernelGGL(frame_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, a);
+    MMFE_HIP_CHECK(hipGetLastError());
+    return MMFE_OK;
+}
+
+int fill_pad_rows(float* out, int64_t n_rows, int64_t out_frames, int64_t first_pad_frame, int64_t n_feat, int layout,
+                  float value, hipStream_t stream) {
+    if (n_rows <= 0 || first_pad_frame >= out_frames) return MMFE_OK;
+    const int64_t total = n_rows * (out_frames - first_pad_frame) * n_feat;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, out, n_rows, out_frames,
+                       first_pad_frame, n_feat, layout, value);
+    MMFE_HIP_CHECK(hipGetLastError());
+    return MMFE_OK;
+}
+
+int feature_sums_launch(const float* x, int64_t n, double* sums, hipStream_t stream) {
+    if (n <= 0) return MMFE_OK;
+    if (reinterpret_cast<uintptr_t>(x) % 16 != 0) {
+        set_error("feature_sums: input must be 16-byte aligned");
+        return MMFE_EINVAL;
+    }
+    hipLaunchKernelGGL(sums_kernel, dim3(grid_for(n / 4 + 1, 256 * 8)), dim3(256), 0, stream, x, n, sums);
+    MMFE_HIP_CHECK(hipGetLastError());
+    return MMFE_OK;
+}
+
+}  // namespace mmfe

@@ -1,0 +1,284 @@
+// C ABI of libmmfe.so: plan management, shape rules, dispatch to the kernel families.
+#include "mmfe_internal.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+namespace mmfe {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+namespace {
+
+int natural_frames(const mmfe_spec& s, int64_t n, int64_t* frames) {
+    int64_t f = 0;
+    switch (s.frames_mode) {
+        case MMFE_FRAMES_SNIP:
+            f = n < s.win_len ? 0 : 1 + (n - s.win_len) / s.hop;
+            break;
+        case MMFE_FRAMES_CENTER: {
+            const int64_t padded = n + 2 * (int64_t)(s.n_fft / 2);
+            f = padded < s.n_fft ? 0 : 1 + (padded - s.n_fft) / s.hop;
+            break;
+        }
+        case MMFE_FRAMES_SCIPY: {
+            const int64_t ext = n + 2 * (int64_t)(s.win_len / 2);
+            if (ext < s.win_len) { f = 0; break; }
+            int64_t nadd = (-(ext - s.win_len)) % s.hop;
+            if (nadd < 0) nadd += s.hop;
+            nadd %= s.win_len;
+            f = 1 + (ext + nadd - s.win_len) / s.hop;
+            break;
+        }
+        case MMFE_FRAMES_CEIL:
+            f = n <= s.win_len ? 1 : 1 + (n - s.win_len + s.hop - 1) / s.hop;
+            break;
+        default:
+            set_error("unknown frames_mode %d", s.frames_mode);
+            return MMFE_EINVAL;
+    }
+    *frames = f;
+    return MMFE_OK;
+}
+
+int validate_spec(const mmfe_spec* s) {
+    if (s == nullptr) { set_error("spec is NULL"); return MMFE_EINVAL; }
+    if (s->struct_size != (int32_t)sizeof(mmfe_spec)) {
+        set_error("mmfe_spec.struct_size is %d, this library expects %d", s->struct_size, (int)sizeof(mmfe_spec));
+        return MMFE_EINVAL;
+    }
+    if (s->kind < MMFE_KIND_FBANK || s->kind > MMFE_KIND_FRAME) { set_error("unknown kind %d", s->kind); return MMFE_EINVAL; }
+    if (s->hop < 1) { set_error("hop must be >= 1"); return MMFE_EINVAL; }
+    if (s->win_len < 1) { set_error("win_len must be >= 1"); return MMFE_EINVAL; }
+    if (s->kind != MMFE_KIND_FRAME) {
+        if (s->n_fft < 2) { set_error("n_fft must be >= 2"); return MMFE_EINVAL; }
+        if (s->win_off < 0 || s->win_off + s->win_len > s->n_fft) { set_error("window does not fit in n_fft"); return MMFE_EINVAL; }
+        if (s->power != 1 && s->power != 2) { set_error("power must be 1 or 2"); return MMFE_EINVAL; }
+        if (s->n_mel < 0) { set_error("n_mel must be >= 0"); return MMFE_EINVAL; }
+        if (s->log_kind < MMFE_LOG_NONE || s->log_kind > MMFE_LOG_LOG10_MAX) { set_error("unknown log_kind"); return MMFE_EINVAL; }
+        if (s->layout != MMFE_LAYOUT_TIME_MAJOR && s->layout != MMFE_LAYOUT_FEAT_MAJOR) { set_error("unknown layout"); return MMFE_EINVAL; }
+        if (s->pad_mode < MMFE_PAD_NONE || s->pad_mode > MMFE_PAD_REFLECT) { set_error("unknown pad_mode"); return MMFE_EINVAL; }
+    }
+    if (s->out_frames < 0) { set_error("out_frames must be >= 0"); return MMFE_EINVAL; }
+    return MMFE_OK;
+}
+
+int out_shape(const mmfe_spec& s, int64_t n, int64_t* natural, int64_t* frames, int64_t* feat) {
+    int64_t f = 0;
+    int rc = natural_frames(s, n, &f);
+    if (rc) return rc;
+    if (s.drop_last && f > 0) f -= 1;
+    *natural = f;
+    *frames = s.out_frames > 0 ? s.out_frames : f;
+    if (s.kind == MMFE_KIND_FRAME) *feat = s.win_len;
+    else *feat = s.n_mel > 0 ? s.n_mel : s.n_fft / 2 + 1;
+    return MMFE_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+        target = dev;
+    }
+    ~DeviceGuard() { if (prev >= 0 && prev != target) (void)hipSetDevice(prev); }
+    int target = -1;
+};
+
+void free_plan(Plan* p) {
+    if (p == nullptr) return;
+    (void)hipFree(p->d_window); (void)hipFree(p->d_tw_a); (void)hipFree(p->d_tw_b); (void)hipFree(p->d_tw64); (void)hipFree(p->d_window64);
+    (void)hipFree(p->d_mel_start); (void)hipFree(p->d_mel_w);
+    (void)hipFree(p->d_band_start); (void)hipFree(p->d_band_len); (void)hipFree(p->d_band_off); (void)hipFree(p->d_band_w);
+    (void)hipFree(p->d_rowmax);
+    delete p;
+}
+
+int run_common(const Plan* plan, const RowSource& src, int64_t n_rows, int64_t n_samples, float* out, void* hip_stream) {
+    if (plan == nullptr) { set_error("plan is NULL"); return MMFE_EINVAL; }
+    if (n_rows < 0 || n_samples < 0) { set_error("negative size"); return MMFE_EINVAL; }
+    if (n_rows == 0) return MMFE_OK;
+    if (src.base == nullptr || out == nullptr) { set_error("NULL data pointer"); return MMFE_EINVAL; }
+    const mmfe_spec& s = plan->spec;
+    int64_t natural = 0, frames = 0, feat = 0;
+    int rc = out_shape(s, n_samples, &natural, &frames, &feat);
+    if (rc) return rc;
+    if (frames == 0) return MMFE_OK;
+    DeviceGuard guard(plan->device);
+    if (!guard.ok) { set_error("cannot make device %d current", plan->device); return MMFE_EHIP; }
+    hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+    switch (plan->impl) {
+        case IMPL_FBANK512: rc = fbank512_launch(*plan, src, n_rows, n_samples, natural, frames, out, stream); break;
+        case IMPL_DFT_GENERIC: rc = dftgen_launch(*plan, src, n_rows, n_samples, natural, frames, out, stream); break;
+        case IMPL_STFT32: rc = stft32_launch(*plan, src, n_rows, n_samples, frames, out, stream); break;
+        case IMPL_FRAME: rc = frame_launch(*plan, src, n_rows, n_samples, frames, out, stream); break;
+        default: set_error("plan has no implementation"); rc = MMFE_EINVAL;
+    }
+    if (rc) return rc;
+    if (natural < frames) {
+        const float v = (s.pad_value + s.out_shift) * s.out_scale;
+        rc = fill_pad_rows(out, n_rows, frames, natural, feat, s.layout, v, stream);
+    }
+    return rc;
+}
+
+}  // namespace
+}  // namespace mmfe
+
+using namespace mmfe;
+
+extern "C" {
+
+int mmfe_abi_version(void) { return MMFE_ABI_VERSION; }
+
+const char* mmfe_last_error(void) { return g_last_error.c_str(); }
+
+int mmfe_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int mmfe_spec_out_shape(const mmfe_spec* spec, int64_t n_samples, int64_t* n_frames, int64_t* n_feat) {
+    int rc = validate_spec(spec);
+    if (rc) return rc;
+    if (n_samples < 0 || n_frames == nullptr || n_feat == nullptr) { set_error("bad argument"); return MMFE_EINVAL; }
+    int64_t natural = 0;
+    return out_shape(*spec, n_samples, &natural, n_frames, n_feat);
+}
+
+int mmfe_plan_create(const mmfe_spec* spec, const void* window, const int32_t* band_start, const int32_t* band_len,
+                     const float* band_weights, int device, mmfe_plan** out_plan) {
+    if (out_plan == nullptr) { set_error("out_plan is NULL"); return MMFE_EINVAL; }
+    *out_plan = nullptr;
+    int rc = validate_spec(spec);
+    if (rc) return rc;
+    if (window == nullptr) { set_error("window is NULL"); return MMFE_EINVAL; }
+    if (spec->kind != MMFE_KIND_FRAME && spec->n_mel > 0 && (band_start == nullptr || band_len == nullptr || band_weights == nullptr)) {
+        set_error("n_mel > 0 needs band_start, band_len and band_weights");
+        return MMFE_EINVAL;
+    }
+    const int ndev = mmfe_device_count();
+    if (ndev <= 0) { set_error("no HIP device available: this library has no CPU path"); return MMFE_ENODEVICE; }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (%d devices)", device, ndev); return MMFE_ENODEVICE; }
+
+    Plan* p = new (std::nothrow) Plan();
+    if (p == nullptr) { set_error("out of host memory"); return MMFE_ENOMEM; }
+    p->spec = *spec;
+    p->device = device;
+    p->n_bins = spec->n_fft / 2 + 1;
+    p->window.resize(spec->win_len);
+    p->window64.resize(spec->win_len);
+    for (int i = 0; i < spec->win_len; ++i) {
+        const double w = spec->window_f64 ? static_cast<const double*>(window)[i] : (double)static_cast<const float*>(window)[i];
+        p->window64[i] = w;
+        p->window[i] = (float)w;
+    }
+    if (spec->kind != MMFE_KIND_FRAME && spec->n_mel > 0) {
+        p->band_start.assign(band_start, band_start + spec->n_mel);
+        p->band_len.assign(band_len, band_len + spec->n_mel);
+        int64_t total = 0;
+        for (int m = 0; m < spec->n_mel; ++m) {
+            if (band_len[m] < 0) { set_error("band_len[%d] < 0", m); free_plan(p); return MMFE_EINVAL; }
+            total += band_len[m];
+        }
+        p->band_weights.assign(band_weights, band_weights + total);
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) { set_error("cannot make device %d current", device); free_plan(p); return MMFE_EHIP; }
+
+    switch (spec->kind) {
+        case MMFE_KIND_FBANK:
+            if (spec->frames_mode != MMFE_FRAMES_SNIP || spec->pad_mode != MMFE_PAD_NONE || spec->layout != MMFE_LAYOUT_TIME_MAJOR ||
+                spec->n_mel <= 0 || spec->power != 2 || spec->spec_scale != 1.0f || spec->drop_last || spec->clamp_below_max > 0.f) {
+                set_error("FBANK: needs snip-edges framing, no padding, mel bands, power spectrum, time-major output");
+                rc = MMFE_EINVAL;
+                break;
+            }
+            if (spec->n_fft == 512 && spec->win_off == 0) { p->impl = IMPL_FBANK512; rc = fbank512_prepare(*p); }
+            else { p->impl = IMPL_DFT_GENERIC; rc = dftgen_prepare(*p); }
+            break;
+        case MMFE_KIND_LOGSPEC:
+            if (spec->frames_mode != MMFE_FRAMES_CENTER || spec->pad_mode == MMFE_PAD_NONE) {
+                set_error("LOGSPEC: needs centred framing with zero or reflect padding");
+                rc = MMFE_EINVAL;
+                break;
+            }
+            p->impl = IMPL_DFT_GENERIC;
+            rc = dftgen_prepare(*p);
+            if (rc == MMFE_OK && spec->clamp_below_max > 0.f) {
+                p->rowmax_capacity = 1 << 20;
+                if (hipMalloc((void**)&p->d_rowmax, (size_t)p->rowmax_capacity * sizeof(float)) != hipSuccess) {
+                    set_error("hipMalloc of the row-max scratch failed");
+                    rc = MMFE_ENOMEM;
+                }
+            }
+            break;
+        case MMFE_KIND_STFT_MAG:
+            p->impl = IMPL_STFT32;
+            rc = stft32_prepare(*p);
+            break;
+        case MMFE_KIND_FRAME:
+            if (spec->frames_mode != MMFE_FRAMES_CEIL) { set_error("FRAME: needs MMFE_FRAMES_CEIL"); rc = MMFE_EINVAL; break; }
+            p->impl = IMPL_FRAME;
+            rc = upload(&p->d_window, p->window);
+            break;
+        default:
+            rc = MMFE_EINVAL;
+    }
+    if (rc) { free_plan(p); return rc; }
+    if (hipDeviceSynchronize() != hipSuccess) { set_error("table upload failed"); free_plan(p); return MMFE_EHIP; }
+    *out_plan = reinterpret_cast<mmfe_plan*>(p);
+    return MMFE_OK;
+}
+
+int mmfe_plan_destroy(mmfe_plan* plan) {
+    Plan* p = reinterpret_cast<Plan*>(plan);
+    if (p == nullptr) return MMFE_OK;
+    DeviceGuard guard(p->device);
+    free_plan(p);
+    return MMFE_OK;
+}
+
+int mmfe_run(const mmfe_plan* plan, const float* in, int64_t in_stride, int64_t n_rows, int64_t n_samples, float* out,
+             void* hip_stream) {
+    if (in_stride < n_samples && n_rows > 1) { set_error("in_stride (%lld) smaller than n_samples (%lld)", (long long)in_stride, (long long)n_samples); return MMFE_EINVAL; }
+    RowSource src{in, in_stride, nullptr, nullptr, nullptr};
+    return run_common(reinterpret_cast<const Plan*>(plan), src, n_rows, n_samples, out, hip_stream);
+}
+
+int mmfe_run_slices(const mmfe_plan* plan, const float* recs, const int64_t* rec_start, const int32_t* rec_index,
+                    const int64_t* offsets, int64_t n_rows, int64_t n_samples, float* out, void* hip_stream) {
+    if (rec_start == nullptr || rec_index == nullptr || offsets == nullptr) { set_error("NULL slice table"); return MMFE_EINVAL; }
+    const Plan* p = reinterpret_cast<const Plan*>(plan);
+    if (p != nullptr && p->impl == IMPL_STFT32) { set_error("slices are not supported for STFT_MAG plans"); return MMFE_EINVAL; }
+    RowSource src{recs, 0, rec_start, rec_index, offsets};
+    return run_common(p, src, n_rows, n_samples, out, hip_stream);
+}
+
+int mmfe_feature_sums(const float* x, int64_t n, double* sums, int device, void* hip_stream) {
+    if (x == nullptr || sums == nullptr || n < 0) { set_error("bad argument"); return MMFE_EINVAL; }
+    const int ndev = mmfe_device_count();
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (%d devices)", device, ndev); return MMFE_ENODEVICE; }
+    DeviceGuard guard(device);
+    if (!guard.ok) { set_error("cannot make device %d current", device); return MMFE_EHIP; }
+    return feature_sums_launch(x, n, sums, reinterpret_cast<hipStream_t>(hip_stream));
+}
+
+}  // extern "C"

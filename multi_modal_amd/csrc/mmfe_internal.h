@@ -1,0 +1,112 @@
+// Internal declarations shared by the translation units of libmmfe.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "mmfe.h"
+
+namespace mmfe {
+
+void set_error(const char* fmt, ...);
+
+#define MMFE_HIP_CHECK(expr)                                                              \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            ::mmfe::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return MMFE_EHIP;                                                             \
+        }                                                                                 \
+    } while (0)
+
+// Where the rows of a batch live.  Either a strided 2-D array, or slices of packed recordings.
+struct RowSource {
+    const float* base;         // strided: row r at base + r*stride.  slices: packed recordings
+    int64_t stride;
+    const int64_t* rec_start;  // slices only (device)
+    const int32_t* rec_index;  // slices only (device)
+    const int64_t* offsets;    // slices only (device)
+};
+
+__device__ __forceinline__ const float* row_ptr(const RowSource& s, int64_t r) {
+    if (s.offsets == nullptr) return s.base + r * s.stride;
+    return s.base + s.rec_start[s.rec_index[r]] + s.offsets[r];
+}
+
+// ---------------------------------------------------------------------------------------------
+// mel filter bank in the layout the radix kernels consume: filters are taken 16 at a time
+// ("pass" j holds filters 16j .. 16j+15, one per lane of a 16-lane frame group); inside a pass
+// every lane walks the same number of taps (the longest band of the pass), shorter bands are
+// padded with zero weights.
+struct MelPassTable {
+    static constexpr int kMaxPass = 16;      // up to 256 filters
+    int n_pass = 0;
+    int niter[kMaxPass] = {0};               // taps walked in pass j
+    int woff[kMaxPass] = {0};                // first tap row of pass j in `weights` (rows of 16 floats)
+    int total_rows = 0;
+    std::vector<int32_t> start;              // n_pass*16 first bins (clamped so start+niter stays in the spectrum buffer)
+    std::vector<float> weights;              // total_rows*16
+};
+
+struct Plan {
+    mmfe_spec spec;
+    int device = -1;
+    int n_bins = 0;
+    // host copies
+    std::vector<float> window;        // fp32 view of the window
+    std::vector<double> window64;     // the window as given (float64 when the caller supplied doubles)
+    std::vector<int32_t> band_start, band_len;
+    std::vector<float> band_weights;
+    MelPassTable mel16;
+    // device tables (plan lifetime)
+    float* d_window = nullptr;        // n_fft floats: window placed at win_off, zeros elsewhere (pre-scaled where a kernel says so)
+    float* d_tw_a = nullptr;          // kernel-specific twiddle table A
+    float* d_tw_b = nullptr;          // kernel-specific twiddle table B
+    double* d_tw64 = nullptr;         // float64 twiddle table (any-length DFT kernel)
+    double* d_window64 = nullptr;     // float64 window (any-length DFT kernel)
+    int32_t* d_mel_start = nullptr;
+    float* d_mel_w = nullptr;
+    int32_t* d_band_start = nullptr;  // plain CSR copy (generic DFT kernel)
+    int32_t* d_band_len = nullptr;
+    int32_t* d_band_off = nullptr;
+    float* d_band_w = nullptr;
+    float* d_rowmax = nullptr;        // scratch for clamp_below_max (allocated lazily at plan creation for a max batch)
+    int64_t rowmax_capacity = 0;
+    int impl = 0;                     // which kernel family serves this plan
+};
+
+enum Impl { IMPL_FBANK512 = 1, IMPL_STFT32 = 2, IMPL_DFT_GENERIC = 3, IMPL_FRAME = 4 };
+
+// launchers (one per translation unit)
+int fbank512_prepare(Plan& plan);
+int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames_natural,
+                    int64_t out_frames, float* out, hipStream_t stream);
+
+int stft32_prepare(Plan& plan);
+int stft32_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames,
+                  float* out, hipStream_t stream);
+
+int dftgen_prepare(Plan& plan);
+int dftgen_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames_natural,
+                  int64_t out_frames, float* out, hipStream_t stream);
+
+int frame_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames,
+                 float* out, hipStream_t stream);
+
+int fill_pad_rows(float* out, int64_t n_rows, int64_t out_frames, int64_t first_pad_frame, int64_t n_feat, int layout,
+                  float value, hipStream_t stream);
+
+int feature_sums_launch(const float* x, int64_t n, double* sums, hipStream_t stream);
+
+template <typename T>
+int upload(T** dptr, const std::vector<T>& host) {
+    *dptr = nullptr;
+    if (host.empty()) return MMFE_OK;
+    MMFE_HIP_CHECK(hipMalloc((void**)dptr, host.size() * sizeof(T)));
+    MMFE_HIP_CHECK(hipMemcpy(*dptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return MMFE_OK;
+}
+
+}  // namespace mmfe

@@ -1,0 +1,132 @@
+"""EPIC-Kitchens audio front-end on MI355X.
+
+Drop-ins for EPICKitchen._log_specgram and the slice arithmetic of EPICKitchen._extract_sound_feature
+(classification/recognition/dataset/epic_kitchen.py:114-154; identical code at
+classification/retrieval/dataset/epic_kitchen.py:141-181) and for the Spec transform chain
+Stack -> ToTorchFormatTensor(div=True) -> GroupNormalize([0],[1])
+(classification/recognition/dataset/transform.py:253-285, wired at epic_kitchen.py:62-66).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _native as N
+from . import melbank
+from .plans import cached_plan, require_gpu, run_rows, to_device_rows
+
+N_FFT = 511               # epic_kitchen.py:119
+RESAMPLING_RATE = 24000   # epic_kitchen.py:77
+HALF_SPAN_SEC = 0.639     # epic_kitchen.py:131-132
+EDGE_SEC = 1.279          # epic_kitchen.py:147,150
+
+
+def _logspec_plan(device: int, nperseg: int, hop: int, eps: float, out_scale: float) -> N.Plan:
+    key = ("epic", nperseg, hop, float(eps), float(out_scale))
+
+    def build(dev: int) -> N.Plan:
+        if nperseg > N_FFT:
+            raise ValueError(f"win_length {nperseg} larger than n_fft {N_FFT}")
+        spec = N.make_spec(kind=N.KIND_LOGSPEC, n_fft=N_FFT, win_len=nperseg, win_off=(N_FFT - nperseg) // 2, hop=hop,
+                           pad_mode=N.PAD_ZERO, frames_mode=N.FRAMES_CENTER, n_mel=0, power=2,
+                           log_kind=N.LOG_LN_ADD, log_floor=float(eps), out_shift=0.0, out_scale=out_scale,
+                           layout=N.LAYOUT_FEAT_MAJOR, window_f64=1)
+        win = melbank.periodic_hann(nperseg)      # float64, multiplied in float64 like librosa does
+        return N.Plan(spec, win, device=dev)
+
+    return cached_plan(key, device, build)
+
+
+def _params(window_size, step_size, resampling_rate):
+    nperseg = int(round(window_size * resampling_rate / 1e3))
+    hop = int(round(step_size * resampling_rate / 1e3))
+    return nperseg, hop
+
+
+def log_specgram_batch(audio: torch.Tensor, window_size: int = 10, step_size: int = 5, eps: float = 1e-6,
+                       resampling_rate: int = RESAMPLING_RATE, div255: bool = False,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(B, n) slices -> (B, 256, 1 + (n-1)//hop) log power spectrograms (frequency-major), one launch.
+    div255=True folds the ToTorchFormatTensor division in, giving what the encoder consumes."""
+    x, origin = to_device_rows(audio)
+    nperseg, hop = _params(window_size, step_size, resampling_rate)
+    plan = _logspec_plan(x.device.index, nperseg, hop, eps, 1.0 / 255.0 if div255 else 1.0)
+    y = run_rows(plan, x, out)
+    return y if origin.type == "cuda" else y.to(origin)
+
+
+def log_specgram(audio, window_size: int = 10, step_size: int = 5, eps: float = 1e-6,
+                 resampling_rate: int = RESAMPLING_RATE):
+    """_log_specgram(self, audio, window_size=10, step_size=5, eps=1e-6): (n,) -> (256, frames).
+    numpy in -> numpy out, tensor in -> tensor out (on the tensor's device)."""
+    is_np = isinstance(audio, np.ndarray)
+    t = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float32)) if is_np else audio
+    if t.dim() != 1:
+        raise ValueError(f"expected a 1-D audio slice, got {tuple(t.shape)}")
+    y = log_specgram_batch(t[None, :], window_size, step_size, eps, resampling_rate)[0]
+    return y.numpy() if is_np else y
+
+
+def spec_to_tensor(spec) -> torch.Tensor:
+    """The Spec transform chain applied to one (H, W) float image: (1, H, W) / 255, mean 0 / std 1."""
+    t = torch.from_numpy(np.ascontiguousarray(spec)) if isinstance(spec, np.ndarray) else spec
+    return (t.to(torch.float32).unsqueeze(0) / 255 - 0.0) / 1.0
+
+
+def sound_slice_bounds(start_frame: int, idx: int, fps_spec: float, n_total: int,
+                       resampling_rate: int = RESAMPLING_RATE) -> Tuple[int, int]:
+    """[left, right) sample range _extract_sound_feature cuts from a recording of n_total samples
+    (epic_kitchen.py:130-152): +-0.639 s around the frame's time stamp, clamped to the first / last
+    round(1.279 * sr) samples at the edges."""
+    centre_sec = (start_frame + idx) / fps_spec
+    left_sec = centre_sec - HALF_SPAN_SEC
+    right_sec = centre_sec + HALF_SPAN_SEC
+    duration = n_total / float(resampling_rate)
+    edge = int(round(resampling_rate * EDGE_SEC))
+    if left_sec < 0:
+        return 0, min(edge, n_total)
+    if right_sec > duration:
+        return max(n_total - edge, 0), n_total
+    return int(round(left_sec * resampling_rate)), int(round(right_sec * resampling_rate))
+
+
+def extract_sound_features(recordings: Sequence[torch.Tensor], rec_index: Sequence[int], start_frame: Sequence[int],
+                           idx: Sequence[int], fps_spec: Sequence[float], resampling_rate: int = RESAMPLING_RATE,
+                           div255: bool = True) -> torch.Tensor:
+    """Batched _extract_sound_feature + _log_specgram (+ /255): for sample i the slice of
+    recordings[rec_index[i]] around (start_frame[i] + idx[i]) / fps_spec[i] is transformed straight from
+    the packed device-resident recordings (no per-slice copy).  All slices of one call must have the same
+    length (interior slices are 30 672 samples, edge slices 30 696: call once per length).
+    Returns (B, 1, 256, frames)."""
+    require_gpu()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    recs = [r.to(device=dev, dtype=torch.float32).reshape(-1) for r in recordings]
+    lengths = [int(r.numel()) for r in recs]
+    starts = np.zeros(len(recs), dtype=np.int64)
+    if recs:
+        starts[1:] = np.cumsum(lengths[:-1])
+    packed = torch.cat(recs) if recs else torch.empty(0, device=dev)
+    bounds = [sound_slice_bounds(start_frame[i], idx[i], fps_spec[i], lengths[rec_index[i]], resampling_rate)
+              for i in range(len(rec_index))]
+    sizes = {r - l for l, r in bounds}
+    if len(sizes) != 1:
+        raise ValueError(f"slices of different lengths in one call: {sorted(sizes)}")
+    n = sizes.pop()
+    nperseg, hop = _params(10, 5, resampling_rate)
+    plan = _logspec_plan(dev.index, nperseg, hop, 1e-6, 1.0 / 255.0 if div255 else 1.0)
+    frames, feat = plan.out_shape(n)
+    out = torch.empty((len(bounds), 1, feat, frames), dtype=torch.float32, device=dev)
+    if len(bounds) == 0 or frames == 0:
+        return out
+    d_start = torch.from_numpy(starts).to(dev)
+    d_index = torch.tensor(list(rec_index), dtype=torch.int32, device=dev)
+    d_off = torch.tensor([l for l, _ in bounds], dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    plan.run_slices_ptr(packed.data_ptr(), d_start.data_ptr(), d_index.data_ptr(), d_off.data_ptr(), len(bounds), n,
+                        out.data_ptr(), stream)
+    # the index tensors must outlive the asynchronous launch on this stream
+    for t in (packed, d_start, d_index, d_off):
+        t.record_stream(torch.cuda.current_stream(dev))
+    return out

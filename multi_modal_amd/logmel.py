@@ -1,0 +1,42 @@
+"""Long-utterance log-mel front-end (n_fft 400, hop 160, 80 mel bands, 30 s utterances).
+
+These parameters do not occur in the reference (its EPIC audio path uses n_fft 511 / hop 120, see
+epic.py); the configuration is the Whisper-style feature extractor and is offered as a throughput
+configuration of the same kernel set: periodic Hann, centre reflect padding, |X|^2, Slaney mel bank,
+log10(max(., 1e-10)), last frame dropped, per-utterance clamp to (max - 8), (x + 4) / 4, output
+(B, n_mels, frames).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _native as N
+from . import melbank
+from .plans import cached_plan, run_rows, to_device_rows
+
+
+def _plan(device: int, n_fft: int, hop: int, n_mels: int, sr: int) -> N.Plan:
+    key = ("logmel", n_fft, hop, n_mels, sr)
+
+    def build(dev: int) -> N.Plan:
+        fb = melbank.slaney_mel_filters(1 + n_fft // 2, n_mels, sr)
+        bs, bl, bw = melbank.dense_to_bands(fb.astype(np.float32))
+        spec = N.make_spec(kind=N.KIND_LOGSPEC, n_fft=n_fft, win_len=n_fft, win_off=0, hop=hop, pad_mode=N.PAD_REFLECT,
+                           frames_mode=N.FRAMES_CENTER, n_mel=n_mels, power=2, log_kind=N.LOG_LOG10_MAX,
+                           log_floor=1e-10, out_shift=4.0, out_scale=0.25, drop_last=1, clamp_below_max=8.0,
+                           layout=N.LAYOUT_FEAT_MAJOR, window_f64=1)
+        return N.Plan(spec, melbank.periodic_hann(n_fft), bs, bl, bw, device=dev)
+
+    return cached_plan(key, device, build)
+
+
+def log_mel_spectrogram(waveforms: torch.Tensor, n_fft: int = 400, hop_length: int = 160, n_mels: int = 80,
+                        sampling_rate: int = 16000, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(B, n) -> (B, n_mels, n // hop_length)."""
+    x, origin = to_device_rows(waveforms)
+    plan = _plan(x.device.index, n_fft, hop_length, n_mels, sampling_rate)
+    y = run_rows(plan, x, out)
+    return y if origin.type == "cuda" else y.to(origin)

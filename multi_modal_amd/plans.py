@@ -1,0 +1,80 @@
+"""Plan cache and the one place where torch tensors meet the C ABI.
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; all arithmetic happens in
+libmmfe.so.  Inputs may live on the CPU (they are copied to the current GPU and the result is copied
+back, like the reference's per-sample CPU call) or on a GPU (result stays there).
+"""
+from __future__ import annotations
+
+import threading
+from typing import Callable, Dict, Hashable, Tuple
+
+import torch
+
+from . import _native as N
+
+_plans: Dict[Hashable, N.Plan] = {}
+_plans_lock = threading.Lock()
+
+
+def require_gpu() -> None:
+    if not torch.cuda.is_available():
+        raise N.MmfeError("multi_modal_amd needs a ROCm GPU (gfx950): torch.cuda.is_available() is False and "
+                          "there is no CPU fallback")
+
+
+def cached_plan(key: Hashable, device: int, build: Callable[[int], N.Plan]) -> N.Plan:
+    k = (key, device)
+    with _plans_lock:
+        plan = _plans.get(k)
+        if plan is None:
+            plan = build(device)
+            _plans[k] = plan
+        return plan
+
+
+def clear_plans() -> None:
+    with _plans_lock:
+        for p in _plans.values():
+            p.close()
+        _plans.clear()
+
+
+def to_device_rows(x: torch.Tensor) -> Tuple[torch.Tensor, torch.device]:
+    """(rows, n) float32 tensor with unit inner stride on a GPU, plus the device the caller's data was on."""
+    require_gpu()
+    origin = x.device
+    if x.dim() != 2:
+        raise ValueError(f"expected a 2-D (rows, samples) tensor, got {tuple(x.shape)}")
+    if x.dtype != torch.float32:
+        x = x.to(torch.float32)
+    if not x.is_cuda:
+        x = x.cuda(non_blocking=False)
+    if x.shape[0] > 1 and (x.stride(1) != 1 or x.stride(0) < x.shape[1]):
+        x = x.contiguous()
+    elif x.stride(1) != 1:
+        x = x.contiguous()
+    return x, origin
+
+
+def run_rows(plan: N.Plan, x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """Run `plan` over the rows of a CUDA tensor (rows, n).  Returns (rows, frames, feat) for time-major
+    plans and (rows, feat, frames) for feature-major ones.  Asynchronous on the current stream."""
+    assert x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
+    rows, n = x.shape
+    frames, feat = plan.out_shape(n)
+    shape = (rows, frames, feat) if plan.spec.layout == N.LAYOUT_TIME_MAJOR or plan.spec.kind == N.KIND_FRAME \
+        else (rows, feat, frames)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    else:
+        if tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+            raise ValueError(f"out must be a contiguous float32 tensor of shape {shape} on {x.device}")
+    if rows == 0 or frames == 0 or feat == 0:
+        return out
+    if x.device.index != plan.device:
+        raise ValueError(f"tensor on {x.device} but plan on cuda:{plan.device}")
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    stride = x.stride(0) if rows > 1 else max(x.stride(0), n)
+    plan.run_ptr(x.data_ptr(), stride, rows, n, out.data_ptr(), stream)
+    return out

@@ -1,0 +1,60 @@
+"""Normalisation statistics of a feature tensor on the device.
+
+Stands for cal_norm (classification/vggsound/dataset/vggsound.py:85-107), which makes two DataLoader
+passes over the data set to obtain the mean and the standard deviation used at vggsound.py:59.  Here the
+sum and the sum of squares are reduced on the GPU in float64; with several ranks two scalars are
+all-reduced instead of gathering features.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import _native as N
+from .plans import require_gpu
+
+
+class RunningNorm:
+    """Accumulates sum / sum of squares / count over batches of features."""
+
+    def __init__(self, device: torch.device = None):
+        require_gpu()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.sums = torch.zeros(2, dtype=torch.float64, device=self.device)
+        self.count = 0
+
+    def update(self, features: torch.Tensor) -> None:
+        x = features
+        if not x.is_cuda:
+            x = x.to(self.device)
+        x = x.to(torch.float32).contiguous()
+        if x.numel() == 0:
+            return
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        N.feature_sums_ptr(x.data_ptr(), x.numel(), self.sums.data_ptr(), x.device.index, stream)
+        self.count += x.numel()
+
+    def finalize(self, group=None) -> Tuple[float, float]:
+        """(mean, std) over everything seen; std is the population standard deviation."""
+        sums = self.sums.clone()
+        count = torch.tensor([float(self.count)], dtype=torch.float64, device=self.device)
+        if dist.is_initialized():
+            packed = torch.cat([sums, count])
+            dist.all_reduce(packed, group=group)
+            sums, count = packed[:2], packed[2:]
+        s, q = sums.tolist()
+        n = float(count.item())
+        if n == 0:
+            return float("nan"), float("nan")
+        mean = s / n
+        var = max(q / n - mean * mean, 0.0)
+        return mean, var ** 0.5
+
+
+def cal_norm(features: torch.Tensor) -> Tuple[float, float]:
+    """Mean and standard deviation of one feature tensor."""
+    r = RunningNorm(features.device if features.is_cuda else None)
+    r.update(features)
+    return r.finalize()

@@ -1,0 +1,243 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Tolerances (floating point; shapes and indices are exact):
+  kaldi log-mel (raw):      p99.9 |d| <= 1e-4, max |d| <= 2e-3  (near-empty 1-2 bin mel filters amplify fp32
+                            FFT rounding; two correct fp32 FFTs cannot agree to 1e-4 max-abs)
+  kaldi log-mel normalised: max |d| <= 5e-4
+  EPIC log spectrogram raw: max |d| <= 1e-4
+  HAR magnitudes:           max |d| <= 1e-6 (values O(1))
+  frame_signal:             bit exact
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mm():
+    import multi_modal_amd as m
+    m.load_library()
+    assert torch.cuda.is_available()
+    return m
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import frontend_oracle
+    return frontend_oracle
+
+
+KINDS = ["noise0.1", "uniform", "sine+noise", "silence", "impulse", "dc", "quiet"]
+HIGH_DYNAMIC_RANGE = ("sine+noise", "dc")
+
+
+def _stats(d):
+    d = np.abs(np.asarray(d, dtype=np.float64)).ravel()
+    return d.max(), np.percentile(d, 99.9)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_vggsound_raw_fbank(mm, O, kind):
+    x = synth(kind, 160000, 1234)
+    ref = O.kaldi_fbank(torch.from_numpy(x)[None], sample_frequency=16000, window_type="hanning", num_mel_bins=128,
+                        frame_shift=25).numpy()
+    got = mm.fbank(torch.from_numpy(x)[None].cuda(), htk_compat=True, sample_frequency=16000, use_energy=False,
+                   window_type="hanning", num_mel_bins=128, dither=0.0, frame_shift=25).cpu().numpy()
+    assert got.shape == ref.shape == (400, 128)
+    mx, p999 = _stats(got - ref)
+    print(kind, "raw fbank max", mx, "p99.9", p999)
+    if kind in HIGH_DYNAMIC_RANGE:
+        # A strong tone / offset next to a 1e-3 noise floor puts most bins at the rounding-noise level of
+        # ANY fp32 FFT of the frame; two fp32 evaluations then differ by more than 1e-4 from each other.
+        # Judge both against the float64 evaluation of the same formula: the HIP path must be as close
+        # to the exact value as the fp32 CPU restatement is (factor 1.5), and still within 2e-3 / 5e-4 of it.
+        exact = O.kaldi_fbank(torch.from_numpy(x)[None], sample_frequency=16000, window_type="hanning",
+                              num_mel_bins=128, frame_shift=25, compute_dtype=torch.float64).numpy()
+        g_mx, g_p = _stats(got - exact)
+        r_mx, r_p = _stats(ref - exact)
+        print(kind, "vs float64: hip max", g_mx, "p99.9", g_p, "| cpu fp32 max", r_mx, "p99.9", r_p)
+        assert g_p <= max(1e-4, 1.5 * r_p) and g_mx <= max(2e-3, 1.5 * r_mx)
+        assert p999 <= 5e-4 and mx <= 4e-3
+    else:
+        assert p999 <= 1e-4 and mx <= 2e-3
+    # mel filter 3 is empty for this bank: exact floor ln(2^-23) in every frame
+    assert np.all(got[:, 3] == np.float32(np.log(np.float32(1.1920929e-07))))
+
+
+def test_vggsound_preprocessing_batch(mm, O):
+    clips = np.stack([synth(k, 160000, 1234 + i) for i, k in enumerate(KINDS)])
+    ref = np.stack([O.preprocessing_audio(torch.from_numpy(c)[None]).numpy() for c in clips])
+    got = mm.preprocessing_audio_batch(torch.from_numpy(clips).cuda()).cpu().numpy()
+    assert got.shape == ref.shape == (len(KINDS), 384, 128)
+    mx, p999 = _stats(got - ref)
+    print("normalised max", mx, "p99.9", p999)
+    assert mx <= 5e-4
+    single = mm.preprocessing_audio(torch.from_numpy(clips[0])[None])       # CPU tensor in -> CPU tensor out
+    assert single.device.type == "cpu" and single.shape == (384, 128)
+    assert np.array_equal(single.numpy(), got[0])
+
+
+@pytest.mark.parametrize("n", [399, 400, 401, 799, 800, 12345, 153600, 200000])
+def test_vggsound_lengths(mm, O, n):
+    """Ragged clip lengths: fewer than 384 frames -> padded rows, more -> cut, n < window -> all padding."""
+    x = synth("noise0.1", n, 7 + n)
+    got = mm.preprocessing_audio(torch.from_numpy(x)[None].cuda()).cpu().numpy()
+    assert got.shape == (384, 128)
+    if n < 400:
+        assert np.allclose(got, 5.1991 / 4.4049, atol=1e-6)
+        return
+    ref = O.preprocessing_audio(torch.from_numpy(x)[None]).numpy()
+    mx, _ = _stats(got - ref)
+    assert mx <= 5e-4
+    m = 1 + (n - 400) // 400
+    if m < 384:
+        assert np.all(got[m:] == got[m, 0])
+
+
+def test_fbank_other_parameters(mm, O):
+    """Other fbank parameter sets: AST-style (povey window, 10 ms shift), 23-bin default, odd offsets."""
+    x = synth("noise0.1", 48000, 99)
+    for kw in [dict(num_mel_bins=128, frame_shift=10.0, window_type="povey"),
+               dict(num_mel_bins=23),
+               dict(num_mel_bins=80, window_type="hamming", frame_length=20.0, frame_shift=7.5, low_freq=0.0, high_freq=-400.0),
+               dict(num_mel_bins=40, remove_dc_offset=False, preemphasis_coefficient=0.0, window_type="rectangular")]:
+        okw = dict(kw)
+        ref = O.kaldi_fbank(torch.from_numpy(x)[None], sample_frequency=16000, **okw).numpy()
+        got = mm.fbank(torch.from_numpy(x)[None].cuda(), sample_frequency=16000, **kw).cpu().numpy()
+        assert got.shape == ref.shape
+        mx, p999 = _stats(got - ref)
+        print(kw, mx, p999)
+        assert p999 <= 1e-4 and mx <= 2e-3
+
+
+def test_fbank_generic_path_non_512(mm, O):
+    """A window that does not round to 512 (8 kHz, 25 ms -> 200 samples -> n_fft 256) goes through the
+    any-length DFT kernel."""
+    x = synth("noise0.1", 16000, 5)
+    ref = O.kaldi_fbank(torch.from_numpy(x)[None], sample_frequency=8000, num_mel_bins=40).numpy()
+    got = mm.fbank(torch.from_numpy(x)[None].cuda(), sample_frequency=8000, num_mel_bins=40).cpu().numpy()
+    assert got.shape == ref.shape
+    mx, p999 = _stats(got - ref)
+    assert p999 <= 1e-4 and mx <= 2e-3
+
+
+def test_fbank_unsupported_raise(mm):
+    x = torch.zeros(1, 16000)
+    for kw in [dict(dither=1.0), dict(use_energy=True), dict(vtln_warp=1.1), dict(snip_edges=False), dict(subtract_mean=True)]:
+        with pytest.raises(NotImplementedError):
+            mm.fbank(x, **kw)
+
+
+@pytest.mark.parametrize("n", [30672, 30696])
+@pytest.mark.parametrize("kind", ["noise0.1", "quiet", "silence", "sine+noise"])
+def test_epic_log_specgram(mm, O, n, kind):
+    x = synth(kind, n, 4242 + n)
+    ref = O.log_specgram(x)
+    got = mm.log_specgram(x)
+    assert isinstance(got, np.ndarray) and got.dtype == np.float32
+    assert got.shape == ref.shape == (256, 256)
+    mx, p999 = _stats(got - ref)
+    print(kind, n, "epic raw max", mx, "p99.9", p999)
+    assert mx <= 1e-4
+    t = mm.spec_to_tensor(got)
+    assert t.shape == (1, 256, 256)
+    assert np.allclose(t.numpy(), O.spec_to_tensor(ref).numpy(), atol=1e-6)
+
+
+def test_epic_batch_div255_and_slices(mm, O):
+    rng = np.random.default_rng(5)
+    recs = [synth("noise0.1", 24000 * 5, 1), synth("uniform", 24000 * 3 + 17, 2)]
+    rec_index = [0, 0, 1, 1, 0]
+    start_frame = [100, 130, 30, 60, 170]
+    idx = [3, 0, 7, 2, 1]
+    fps = [60.0, 60.0, 50.0, 50.0, 60.0]
+    bounds = [O.sound_slice_bounds(start_frame[i], idx[i], fps[i], len(recs[rec_index[i]])) for i in range(5)]
+    assert len({r - l for l, r in bounds}) == 1
+    ref = np.stack([O.spec_to_tensor(O.log_specgram(recs[rec_index[i]][l:r])).numpy() for i, (l, r) in enumerate(bounds)])
+    got = mm.epic.extract_sound_features([torch.from_numpy(r) for r in recs], rec_index, start_frame, idx, fps).cpu().numpy()
+    assert got.shape == ref.shape == (5, 1, 256, 256)
+    assert np.abs(got - ref).max() <= 1e-4 / 255 + 1e-7
+    # edge slices (clamped to the first / last 30696 samples)
+    b0 = O.sound_slice_bounds(0, 0, 60.0, len(recs[0]))
+    b1 = O.sound_slice_bounds(10 ** 6, 0, 60.0, len(recs[0]))
+    assert b0 == (0, 30696) and b1 == (len(recs[0]) - 30696, len(recs[0]))
+    got = mm.epic.extract_sound_features([torch.from_numpy(recs[0])], [0, 0], [0, 10 ** 6], [0, 0], [60.0, 60.0]).cpu().numpy()
+    for i, (l, r) in enumerate([b0, b1]):
+        ref = O.spec_to_tensor(O.log_specgram(recs[0][l:r])).numpy()
+        assert np.abs(got[i] - ref).max() <= 1e-4 / 255 + 1e-7
+
+
+@pytest.mark.parametrize("shape", [(6, 192), (15, 1003), (3, 2, 64), (1, 31), (2, 4), (5, 33)])
+def test_har_stft_mag(mm, O, shape):
+    rng = np.random.default_rng(4321)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = O.stft_mag(x)
+    got = mm.stft_mag(x)
+    assert isinstance(got, np.ndarray) and got.dtype == np.float32
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 1e-6
+
+
+def test_har_against_scipy(mm):
+    import scipy.signal
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((64, 6, 192)).astype(np.float32)
+    ref = np.abs(scipy.signal.stft(x, fs=100, nperseg=32, noverlap=28)[-1])
+    got = mm.stft_mag(torch.from_numpy(x).cuda(), fs=100, nperseg=32, noverlap=28).cpu().numpy()
+    assert got.shape == ref.shape == (64, 6, 17, 49)
+    assert np.abs(got - ref).max() <= 1e-6
+
+
+@pytest.mark.parametrize("shape,fl,hop", [((1, 10), 4, 3), ((2, 16000), 400, 160), ((3,), 8, 2), ((2, 3, 100), 16, 7),
+                                          ((5,), 5, 2), ((7,), 5, 3)])
+def test_frame_signal(mm, O, shape, fl, hop):
+    rng = np.random.default_rng(3)
+    s = torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+    w = torch.from_numpy(rng.standard_normal(fl).astype(np.float32))
+    ref = O.frame_signal(s, fl, hop, w)
+    got = mm.frame_signal(s.cuda(), fl, hop, w.cuda()).cpu()
+    assert got.shape == ref.shape
+    assert torch.equal(got, ref)
+    assert torch.equal(mm.frame_signal(s, fl, hop).cpu(), O.frame_signal(s, fl, hop))
+    with pytest.raises(ValueError):
+        mm.frame_signal(s, fl, hop, torch.ones(fl + 1))
+
+
+def test_long_utterance_logmel(mm, O):
+    x = np.stack([synth("noise0.1", 480000, 99), synth("sine+noise", 480000, 100)])
+    ref = np.stack([O.whisper_logmel(c) for c in x])
+    got = mm.logmel.log_mel_spectrogram(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert got.shape == ref.shape == (2, 80, 3000)
+    mx, p999 = _stats(got - ref)
+    print("logmel max", mx, p999)
+    assert mx <= 1e-4
+
+
+def test_cal_norm(mm):
+    rng = np.random.default_rng(0)
+    f = torch.from_numpy(rng.standard_normal((7, 384, 128)).astype(np.float32) * 4.4 - 5.2)
+    mean, std = mm.stats.cal_norm(f.cuda())
+    assert abs(mean - f.double().mean().item()) < 1e-9 * 1e3
+    assert abs(std - f.double().std(unbiased=False).item()) < 1e-6
+
+
+def test_full_size_properties(mm):
+    """BASELINE configuration 2 at full size (4096 clips): properties that do not need the oracle.
+    Every clip is one of 8 distinct waveforms, so equal clips must give bit-identical features wherever
+    they sit in the batch, and the 8 distinct ones are checked against the small-batch result."""
+    base = torch.from_numpy(np.stack([synth("noise0.1", 160000, 1234 + i) for i in range(8)])).cuda()
+    small = mm.preprocessing_audio_batch(base)
+    big_in = base.repeat(512, 1)
+    big = mm.preprocessing_audio_batch(big_in)
+    assert big.shape == (4096, 384, 128)
+    assert torch.equal(big.view(512, 8, 384, 128), small.unsqueeze(0).expand(512, -1, -1, -1))
+    assert torch.isfinite(big).all()
+    # linearity of the pre-log pipeline: scaling the waveform by 2 adds ln(4) to every un-floored cell
+    a = mm.fbank_batch(base[:2], sample_frequency=16000, window_type="hanning", num_mel_bins=128, frame_shift=25)
+    b = mm.fbank_batch(base[:2] * 2.0, sample_frequency=16000, window_type="hanning", num_mel_bins=128, frame_shift=25)
+    mask = a > -15.0
+    assert torch.allclose((b - a)[mask], torch.full_like(a[mask], float(np.log(4.0))), atol=2e-5)
