@@ -63,6 +63,10 @@ class MmfeSpec(ctypes.Structure):
 
 
 def library_path() -> str:
+    """libmmfe.so next to this file; MMFE_LIBRARY_PATH selects another build of the same ABI (kernel tuning)."""
+    override = os.environ.get("MMFE_LIBRARY_PATH")
+    if override:
+        return override
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 
 

@@ -5,7 +5,8 @@
 // vggsound.py:48-59: per frame  DC removal -> pre-emphasis -> window -> zero-pad to 512 ->
 // real FFT -> |X|^2 -> banded mel -> ln(max(.,floor)) -> (x+shift)*scale, stored time-major.
 //
-// Mapping: 16 lanes own one frame, so a wave64 carries 4 frames through the whole pipeline.
+// Mapping: 16 lanes own one frame, so a wave64 carries 4 consecutive frames of one clip through the
+// whole pipeline.
 //   * the 512-point real FFT is a 256-point complex FFT of z[n] = y[2n] + i*y[2n+1], split 16 x 16:
 //     lane b runs a register-resident 16-point FFT over z[16a+b], twiddles by W256^(b*c), the 16
 //     lanes transpose through a padded LDS tile, lane c runs the second 16-point FFT and holds
@@ -13,8 +14,13 @@
 //   * Z goes back to LDS in natural order, each lane picks up the pairs (k, 256-k) it needs for the
 //     real-FFT recombination, shares E = Z[k]+conj(Z[256-k]) and D = Z[k]-conj(Z[256-k]) between the
 //     two bins, and leaves |X|^2 in LDS;
-//   * the mel projection walks the bands 16 filters at a time (one filter per lane) with zero-padded
-//     per-pass tap tables, so the spectrum never leaves the CU.
+//   * banded mel projection, two forms:
+//       - matrix-pipe form: v_mfma_f32_4x4x1 runs 16 independent 4x4 outer-product blocks; block
+//         `blk` accumulates (4 frames of the wave) x (filters 4*blk..4*blk+3) over ITS OWN run of
+//         bins, one bin per instruction, weights resident in VGPRs.  Two instruction streams cover
+//         128 filters.  The f32 MFMA is a k-ordered fmaf chain, so the numerics equal the scalar
+//         form; it only moves the banded projection off the VALU and off the LDS latency chain.
+//       - VALU form (any filter bank): 16 filters at a time, one per lane, zero-padded tap tables.
 // HBM traffic is the algorithmic minimum: every kept sample is read once (8-byte lane loads that
 // cover each frame's 128-byte lines exactly once) and every output float is written once.
 #include "mmfe_internal.h"
@@ -22,16 +28,26 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace mmfe {
 
 namespace {
 
 constexpr int kFrameLds = 16 * 17 * 8;       // bytes of LDS work space per frame (padded 16x16 complex tile)
-constexpr int kFrameFloats = kFrameLds / 4;
-constexpr int kWavesPerBlock = 4;
+constexpr int kFrameFloats = kFrameLds / 4;  // 544
+constexpr int kPGuard = 8;                   // floats in front of the power spectrum (bin runs may start below 0)
+#ifndef MMFE_FBANK_WAVES
+#define MMFE_FBANK_WAVES 4
+#endif
+#ifndef MMFE_FBANK_MIN_WAVES_PER_SIMD
+#define MMFE_FBANK_MIN_WAVES_PER_SIMD 3
+#endif
+constexpr int kWavesPerBlock = MMFE_FBANK_WAVES;
 constexpr int kTwPostEntries = 144;          // -i*W512^k for k = 0..143
 constexpr int kMaxPass = MelPassTable::kMaxPass;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct FbankArgs {
     RowSource src;
@@ -42,10 +58,6 @@ struct FbankArgs {
     int hop;
     int win_len;
     int n_mel;
-    int n_pass;
-    int mel_rows;          // total tap rows (of 16 weights)
-    int niter[kMaxPass];
-    int woff[kMaxPass];
     float preemph;
     int remove_dc;
     float inv_win_len;
@@ -56,97 +68,129 @@ struct FbankArgs {
     const float* window;       // 512 floats, pre-halved, zero beyond win_len
     const float2* tw_stage;    // 256: W256^n
     const float2* tw_post;     // 144: -i*W512^k
+    // VALU mel form
+    int n_pass;
+    int mel_rows;              // total tap rows (of 16 weights)
     const int32_t* mel_start;  // n_pass*16
+    const int32_t* mel_niter;  // n_pass
+    const int32_t* mel_woff;   // n_pass
     const float* mel_w;        // mel_rows*16
+    // matrix-pipe mel form
+    const int32_t* mel4_kstart;  // 2*64: first bin of the run of (set, lane)
+    const float* mel4_w;         // (4*NGA + 4*NGB) * 64 weights, step-major
 };
 
-// Loads the 2-sample slices (32a+2b, 32a+2b+1), a = 0..NA-1, of one frame.
-template <int NA, bool VEC2>
-__device__ __forceinline__ void load_frame(float2 (&v)[NA], const float* fp, bool valid, int b, int win_len) {
+// Loads the 2-sample slices (32a+2b, 32a+2b+1), a = 0..NA-1, of one frame.  Branch-free, so the
+// surrounding loop stays one basic block and the loads can be scheduled freely: a frame slot beyond
+// the row's last frame reads row 0 instead (`safe`; its results are never stored), and lanes of a
+// slice that sits in the zero padding read `safe` and select zero.  EXACT promises
+// 32*(NA-1) < win_len <= 32*NA, so only the last slice needs the per-lane test and all other loads
+// are one base register plus an immediate offset.  The VEC2 form needs an even win_len.
+template <int NA, bool VEC2, bool EXACT>
+__device__ __forceinline__ void load_frame(float2 (&v)[NA], const float* fp, const float* safe, bool valid, int b, int win_len) {
+    const float* base = (valid ? fp : safe) + 2 * b;
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
         const int idx = 32 * a + 2 * b;
-        float2 r = make_float2(0.f, 0.f);
+        const bool whole = EXACT && a < NA - 1;        // compile-time: slice entirely inside the window
         if (VEC2) {
-            if (valid && idx + 1 < win_len) r = *reinterpret_cast<const float2*>(fp + idx);
-            else if (valid && idx < win_len) r.x = fp[idx];
+            const bool ok = whole || idx + 1 < win_len;
+            const float2 r = *reinterpret_cast<const float2*>(ok ? base + 32 * a : safe);
+            v[a] = whole ? r : make_float2(ok ? r.x : 0.f, ok ? r.y : 0.f);
         } else {
-            if (valid && idx < win_len) r.x = fp[idx];
-            if (valid && idx + 1 < win_len) r.y = fp[idx + 1];
+            const bool ok0 = whole || idx < win_len, ok1 = whole || idx + 1 < win_len;
+            const float r0 = *(ok0 ? base + 32 * a : safe);
+            const float r1 = *(ok1 ? base + 32 * a + 1 : safe);
+            v[a] = make_float2(ok0 ? r0 : 0.f, ok1 ? r1 : 0.f);
         }
-        v[a] = r;
     }
 }
 
-// `log_of_floor` is log(floor) rounded on the host, so floored cells carry the same value the
-// reference's CPU libm produces (device logf is within 1 ulp, not correctly rounded).
+// Branch-free log stage.  `log_of_floor` is log(floor) rounded on the host, so floored cells carry the
+// value the reference's CPU libm produces (device logf is within 1 ulp, not correctly rounded).
 __device__ __forceinline__ float apply_log(float x, int kind, float floor_, float log_of_floor) {
-    switch (kind) {
-        case MMFE_LOG_LN_MAX: return x <= floor_ ? log_of_floor : logf(x);
-        case MMFE_LOG_LN_ADD: return logf(x + floor_);
-        case MMFE_LOG_LOG10_MAX: return x <= floor_ ? log_of_floor : log10f(x);
-        default: return x;
-    }
+    const bool is_add = kind == MMFE_LOG_LN_ADD;
+    const bool is_max = kind == MMFE_LOG_LN_MAX || kind == MMFE_LOG_LOG10_MAX;
+    const float arg = is_add ? x + floor_ : fmaxf(x, floor_);
+    float l = logf(arg);
+    if (kind == MMFE_LOG_LOG10_MAX) l *= 0.43429448190325182765f;
+    l = (is_max && x <= floor_) ? log_of_floor : l;
+    return kind == MMFE_LOG_NONE ? x : l;
 }
 
-template <int NA /* ceil(win_len/32) */, bool VEC2>
-__global__ void __launch_bounds__(64 * kWavesPerBlock, 3) fbank512_kernel(const FbankArgs p) {
+template <int NA /* ceil(win_len/32) */, bool VEC2, bool EXACT, int NGA, int NGB /* groups of 4 bins per mel set; NGA == 0: VALU mel */>
+__global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_SIMD) fbank512_kernel(const FbankArgs p) {
+    constexpr bool kMfmaMel = NGA > 0;
+    constexpr int kStepsA = 4 * NGA, kStepsB = 4 * NGB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* s_tw_stage = reinterpret_cast<float2*>(smem);                      // 256
     float2* s_tw_post = s_tw_stage + 256;                                      // 144
     float* s_win = reinterpret_cast<float*>(s_tw_post + kTwPostEntries);       // 512
-    int32_t* s_mel_start = reinterpret_cast<int32_t*>(s_win + 512);            // kMaxPass*16
-    float* s_mel_w = reinterpret_cast<float*>(s_mel_start + kMaxPass * 16);    // mel_rows*16
-    char* s_work = reinterpret_cast<char*>(s_mel_w + p.mel_rows * 16);         // 16-byte aligned: rows of 16 floats
+    int32_t* s_mel_start = reinterpret_cast<int32_t*>(s_win + 512);            // VALU mel only: kMaxPass*16
+    float* s_mel_w = reinterpret_cast<float*>(s_mel_start + (kMfmaMel ? 0 : kMaxPass * 16));   // VALU mel only
+    char* s_work = reinterpret_cast<char*>(s_mel_w + (kMfmaMel ? 0 : p.mel_rows * 16));
 
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_tw_stage[i] = p.tw_stage[i];
     for (int i = threadIdx.x; i < kTwPostEntries; i += blockDim.x) s_tw_post[i] = p.tw_post[i];
     for (int i = threadIdx.x; i < 512; i += blockDim.x) s_win[i] = p.window[i];
-    for (int i = threadIdx.x; i < p.n_pass * 16; i += blockDim.x) s_mel_start[i] = p.mel_start[i];
-    for (int i = threadIdx.x; i < p.mel_rows * 16; i += blockDim.x) s_mel_w[i] = p.mel_w[i];
+    if (!kMfmaMel) {
+        for (int i = threadIdx.x; i < p.n_pass * 16; i += blockDim.x) s_mel_start[i] = p.mel_start[i];
+        for (int i = threadIdx.x; i < p.mel_rows * 16; i += blockDim.x) s_mel_w[i] = p.mel_w[i];
+    }
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fl = lane >> 4;      // frame slot within the wave
     const int b = lane & 15;       // lane within the frame group
-    float2* fbuf = reinterpret_cast<float2*>(s_work + (wave * 4 + fl) * kFrameLds);
-    float* pbuf = reinterpret_cast<float*>(fbuf);
+    char* wave_work = s_work + wave * 4 * kFrameLds;
+    float2* fbuf = reinterpret_cast<float2*>(wave_work + fl * kFrameLds);
+    // power spectrum of frame slot f lives at float offset kPGuard + 8*f of its tile: the 8*f skew keeps
+    // same-index 4-byte accesses of different frame slots on different banks
+    float* pbuf = reinterpret_cast<float*>(fbuf) + kPGuard + 8 * fl;
 
-    const unsigned quads_per_row = (unsigned)(p.frames_valid + 3) >> 2;
-    const unsigned total_quads = (unsigned)p.n_rows * quads_per_row;
-    const unsigned qstride = gridDim.x * kWavesPerBlock;
-    unsigned quad = blockIdx.x * kWavesPerBlock + wave;
-
-    // frame owned by this lane group inside quad q (q is wave-uniform)
-    auto locate = [&](unsigned q, unsigned& row, int& t) -> bool {
-        row = q / quads_per_row;
-        t = (int)(q - row * quads_per_row) * 4 + fl;
-        return q < total_quads && t < p.frames_valid;
-    };
-
-    float2 nxt[NA];
-    {
-        unsigned row; int t;
-        const bool valid = locate(quad, row, t);
-        const float* fp = valid ? row_ptr(p.src, row) + (int64_t)t * p.hop : nullptr;
-        load_frame<NA, VEC2>(nxt, fp, valid, b, p.win_len);
+    // matrix-pipe mel: lane = 4*blk + q supplies A = P[frame slot q][run(blk) + s] and B = weight of
+    // filter (64*set + lane) at that bin; weights stay in registers for the life of the kernel
+    float wreg[kMfmaMel ? kStepsA + kStepsB : 1];
+    const float* pa_A = nullptr;
+    const float* pa_B = nullptr;
+    if (kMfmaMel) {
+#pragma unroll
+        for (int s = 0; s < kStepsA + kStepsB; ++s) wreg[s] = p.mel4_w[s * 64 + lane];
+        const float* slot = reinterpret_cast<const float*>(wave_work + (lane & 3) * kFrameLds) + kPGuard + 8 * (lane & 3);
+        pa_A = slot + p.mel4_kstart[lane];
+        pa_B = slot + p.mel4_kstart[64 + lane];
     }
 
-    for (; quad < total_quads; quad += qstride) {
-        unsigned row; int t;
-        const bool valid = locate(quad, row, t);
+    // work distribution: quad = 4 consecutive frames of one row; a block takes kWavesPerBlock consecutive
+    // quads per round so that its waves stream one contiguous region
+    const unsigned qpr = (unsigned)(p.frames_valid + 3) >> 2;      // quads per row
+    const unsigned qstride = gridDim.x * kWavesPerBlock;
+    const unsigned d_row = qstride / qpr, d_q = qstride - d_row * qpr;
+    const unsigned quad0 = blockIdx.x * kWavesPerBlock + wave;
+    unsigned row = quad0 / qpr, q = quad0 - row * qpr;              // wave-uniform
+    auto advance = [&](unsigned& r, unsigned& qq) {
+        r += d_row;
+        qq += d_q;
+        if (qq >= qpr) { qq -= qpr; r += 1; }
+    };
+
+    const float* safe = row_ptr(p.src, 0);      // first samples of row 0: always readable
+    float2 nxt[NA];
+    {
+        const int t = (int)q * 4 + fl;
+        const bool valid = row < (unsigned)p.n_rows && t < p.frames_valid;
+        const float* fp = row_ptr(p.src, valid ? row : 0) + (int64_t)t * p.hop;
+        load_frame<NA, VEC2, EXACT>(nxt, fp, safe, valid, b, p.win_len);
+    }
+
+    while (row < (unsigned)p.n_rows) {
+        const int t0 = (int)q * 4;          // first frame of the quad
+        const unsigned cur_row = row;
 
         float2 g[NA];
 #pragma unroll
         for (int a = 0; a < NA; ++a) g[a] = nxt[a];
-
-        {   // prefetch the next quad of this wave; the loads stay in flight under the arithmetic below
-            unsigned nrow; int nt;
-            const bool nvalid = locate(quad + qstride, nrow, nt);
-            const float* nfp = nvalid ? row_ptr(p.src, nrow) + (int64_t)nt * p.hop : nullptr;
-            load_frame<NA, VEC2>(nxt, nfp, nvalid, b, p.win_len);
-        }
 
         // ---- per-frame DC removal (kaldi remove_dc_offset) ------------------------------------
         if (p.remove_dc) {
@@ -189,6 +233,15 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) fbank512_kernel(const 
             fbuf[c * 17 + b] = val;
         }
         wave_lds_fence();
+        // prefetch the next quad of this wave here, where register pressure is lowest (the first-half
+        // registers are dead); the loads stay in flight under the second half of this iteration
+        advance(row, q);
+        {
+            const int nt = (int)q * 4 + fl;
+            const bool nvalid = row < (unsigned)p.n_rows && nt < p.frames_valid;
+            const float* nfp = row_ptr(p.src, row < (unsigned)p.n_rows ? row : 0) + (int64_t)nt * p.hop;
+            load_frame<NA, VEC2, EXACT>(nxt, nfp, safe, nvalid, b, p.win_len);
+        }
         float2 u[16];
 #pragma unroll
         for (int bb = 0; bb < 16; ++bb) u[bb] = fbuf[b * 17 + bb];
@@ -222,40 +275,137 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) fbank512_kernel(const 
             pbuf[k] = pk[i];
             pbuf[256 - k] = pq[i];
         }
-        if (b == 0) pbuf[128] = pk[8];
+        pbuf[b == 0 ? 128 : 272 + b] = pk[8];      // only lane 0's ninth pair is bin 128; the others park theirs in unused slots
         wave_lds_fence();
 
         // ---- banded mel projection, log, affine, store ----------------------------------------
-        float* orow = p.out + ((int64_t)row * p.out_rows + t) * p.n_mel;
-        for (int j = 0; j < p.n_pass; ++j) {
-            const int m = 16 * j + b;
-            const float* pp = pbuf + s_mel_start[m];
-            const float* wp = s_mel_w + p.woff[j] * 16 + b;
-            const int n = p.niter[j];
-            float acc = 0.f;
-            for (int i = 0; i < n; ++i) acc = fmaf(wp[16 * i], pp[i], acc);
-            float val = apply_log(acc, p.log_kind, p.log_floor, p.log_of_floor);
-            val = (val + p.out_shift) * p.out_scale;
-            if (valid && m < p.n_mel) orow[m] = val;
+        if (kMfmaMel) {
+            f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < kStepsA; ++s) accA = __builtin_amdgcn_mfma_f32_4x4x1f32(pa_A[s], wreg[s], accA, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < kStepsB; ++s) accB = __builtin_amdgcn_mfma_f32_4x4x1f32(pa_B[s], wreg[kStepsA + s], accB, 0, 0, 0);
+            // lane holds filter (64*set + lane) of the quad's 4 frames in registers 0..3.  Frames past
+            // the row's last frame repeat frame 0's store (same address, same value): no branch.
+            float va[4], vb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                va[r] = (apply_log(accA[r], p.log_kind, p.log_floor, p.log_of_floor) + p.out_shift) * p.out_scale;
+                vb[r] = NGB > 0 ? (apply_log(accB[r], p.log_kind, p.log_floor, p.log_of_floor) + p.out_shift) * p.out_scale : 0.f;
+            }
+            const int n_ok = p.frames_valid - t0;         // >= 1, wave-uniform
+            float* obase = p.out + ((int64_t)cur_row * p.out_rows + t0) * p.n_mel + lane;
+            if (lane < p.n_mel) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) obase[r < n_ok ? r * p.n_mel : 0] = r < n_ok ? va[r] : va[0];
+            }
+            if (NGB > 0 && 64 + lane < p.n_mel) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) obase[64 + (r < n_ok ? r * p.n_mel : 0)] = r < n_ok ? vb[r] : vb[0];
+            }
+        } else {
+            const int t = t0 + fl;
+            const bool valid = t < p.frames_valid;
+            float* orow = p.out + ((int64_t)cur_row * p.out_rows + t) * p.n_mel;
+            for (int j = 0; j < p.n_pass; ++j) {
+                const int m = 16 * j + b;
+                const float* pp = pbuf + s_mel_start[m];
+                const float* wp = s_mel_w + p.mel_woff[j] * 16 + b;
+                const int n = p.mel_niter[j];
+                float acc = 0.f;
+                for (int i = 0; i < n; ++i) acc = fmaf(wp[16 * i], pp[i], acc);
+                float val = apply_log(acc, p.log_kind, p.log_floor, p.log_of_floor);
+                val = (val + p.out_shift) * p.out_scale;
+                if (valid && m < p.n_mel) orow[m] = val;
+            }
         }
         wave_lds_fence();
     }
 }
 
-template <int NA, bool VEC2>
+template <int NA, bool VEC2, bool EXACT, int NGA, int NGB>
 int launch_variant(const FbankArgs& args, int grid, size_t lds, hipStream_t stream) {
-    static bool attr_set = false;   // raising the dynamic-LDS limit is idempotent; racing threads set the same value
-    if (!attr_set) {
-        MMFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fbank512_kernel<NA, VEC2>),
+    // raising the dynamic-LDS limit is idempotent; it is repeated per device on first use
+    static unsigned long long done_mask = 0;
+    int dev = 0;
+    MMFE_HIP_CHECK(hipGetDevice(&dev));
+    if (!(done_mask >> (dev & 63) & 1ull)) {
+        MMFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fbank512_kernel<NA, VEC2, EXACT, NGA, NGB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        done_mask |= 1ull << (dev & 63);
     }
-    hipLaunchKernelGGL((fbank512_kernel<NA, VEC2>), dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, args);
+    hipLaunchKernelGGL((fbank512_kernel<NA, VEC2, EXACT, NGA, NGB>), dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, args);
     MMFE_HIP_CHECK(hipGetLastError());
     return MMFE_OK;
 }
 
+// Instantiated (NGA, NGB) shapes of the matrix-pipe mel form, smallest first.
+struct Mel4Shape { int nga, ngb; };
+constexpr Mel4Shape kMel4Shapes[] = {{2, 7}, {3, 8}, {4, 0}, {8, 0}, {4, 8}};
+
 }  // namespace
+
+// Builds the per-(set, lane) bin runs and the step-major weight table of the matrix-pipe mel form.
+// Returns false when the bank does not fit any instantiated shape (the VALU form is used then).
+static bool build_mel4(Plan& plan, bool align) {
+    const mmfe_spec& s = plan.spec;
+    if (s.n_mel > 128) return false;
+    const int nsets = (s.n_mel + 63) / 64;
+    std::vector<int> boff(s.n_mel + 1, 0);
+    for (int m = 0; m < s.n_mel; ++m) boff[m + 1] = boff[m] + plan.band_len[m];
+    int kstart[2][16];
+    int steps[2] = {0, 0};
+    for (int h = 0; h < 2; ++h) {
+        for (int blk = 0; blk < 16; ++blk) {
+            int kmin = 1 << 30, kmax = -1;
+            for (int j = 0; j < 4; ++j) {
+                const int m = 64 * h + 4 * blk + j;
+                if (h >= nsets || m >= s.n_mel || plan.band_len[m] == 0) continue;
+                kmin = std::min(kmin, (int)plan.band_start[m]);
+                kmax = std::max(kmax, (int)(plan.band_start[m] + plan.band_len[m] - 1));
+            }
+            if (kmax < 0) { kstart[h][blk] = 0; continue; }
+            int ks = kmin;
+            if (align) ks = kmin - (((kmin - blk) % 8 + 8) % 8);     // run start = blk (mod 8): conflict-free LDS reads
+            if (ks < -kPGuard) ks = kmin;
+            kstart[h][blk] = ks;
+            steps[h] = std::max(steps[h], kmax - ks + 1);
+        }
+    }
+    const int ga = (steps[0] + 3) / 4, gb = (steps[1] + 3) / 4;
+    int pick = -1;
+    for (size_t i = 0; i < sizeof(kMel4Shapes) / sizeof(kMel4Shapes[0]); ++i) {
+        if (ga <= kMel4Shapes[i].nga && gb <= kMel4Shapes[i].ngb && ga >= 1) { pick = (int)i; break; }
+    }
+    if (pick < 0) return false;
+    const int NGA = kMel4Shapes[pick].nga, NGB = kMel4Shapes[pick].ngb;
+    const int total_steps = 4 * (NGA + NGB);
+    // every run must stay inside the frame's LDS tile
+    for (int h = 0; h < 2; ++h)
+        for (int blk = 0; blk < 16; ++blk)
+            if (kPGuard + 24 + kstart[h][blk] + 4 * std::max(NGA, NGB) > kFrameFloats) return false;
+    std::vector<int32_t> ks(128, 0);
+    std::vector<float> w((size_t)total_steps * 64, 0.f);
+    for (int h = 0; h < nsets; ++h) {
+        const int nsteps = 4 * (h == 0 ? NGA : NGB);
+        const int soff = h == 0 ? 0 : 4 * NGA;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int blk = lane / 4, m = 64 * h + lane;
+            ks[h * 64 + lane] = kstart[h][blk];
+            if (m >= s.n_mel) continue;
+            for (int st = 0; st < nsteps; ++st) {
+                const int k = kstart[h][blk] + st;
+                const int rel = k - plan.band_start[m];
+                if (rel >= 0 && rel < plan.band_len[m]) w[(size_t)(soff + st) * 64 + lane] = plan.band_weights[boff[m] + rel];
+            }
+        }
+    }
+    plan.mel4_nga = NGA;
+    plan.mel4_ngb = NGB;
+    if (upload(&plan.d_mel4_kstart, ks) != MMFE_OK) return false;
+    if (upload(&plan.d_mel4_w, w) != MMFE_OK) return false;
+    return true;
+}
 
 int fbank512_prepare(Plan& plan) {
     const mmfe_spec& s = plan.spec;
@@ -285,7 +435,23 @@ int fbank512_prepare(Plan& plan) {
     if ((rc = upload(&plan.d_tw_a, tws))) return rc;
     if ((rc = upload(&plan.d_tw_b, twp))) return rc;
 
-    // mel taps, 16 filters per pass
+    for (int m = 0; m < s.n_mel; ++m) {
+        const int st = plan.band_start[m], len = plan.band_len[m];
+        if (len > 0 && (st < 0 || st + len > 257)) {
+            set_error("fbank512: mel band %d = [%d, %d) leaves the 257-bin spectrum", m, st, st + len);
+            return MMFE_EINVAL;
+        }
+    }
+    // matrix-pipe mel form when the bank fits an instantiated shape (MMFE_MEL_FORM=valu forces the VALU form,
+    // MMFE_MEL_ALIGN=0 drops the bank-conflict-free run alignment)
+    const char* form = std::getenv("MMFE_MEL_FORM");
+    const char* al = std::getenv("MMFE_MEL_ALIGN");
+    const bool want_mfma = !(form != nullptr && std::string(form) == "valu");
+    const bool align = !(al != nullptr && std::string(al) == "0");
+    plan.mel4_nga = plan.mel4_ngb = 0;
+    if (want_mfma && !build_mel4(plan, align) && align) (void)build_mel4(plan, false);
+
+    // VALU form tables (always built: they are small and serve as the general path)
     MelPassTable& mt = plan.mel16;
     mt.n_pass = (s.n_mel + 15) / 16;
     mt.start.assign(mt.n_pass * 16, 0);
@@ -310,13 +476,9 @@ int fbank512_prepare(Plan& plan) {
             if (m >= s.n_mel) continue;
             int st = plan.band_start[m];
             const int len = plan.band_len[m];
-            if (len > 0 && (st < 0 || st + len > 257)) {
-                set_error("fbank512: mel band %d = [%d, %d) leaves the 257-bin spectrum", m, st, st + len);
-                return MMFE_EINVAL;
-            }
             if (len == 0) st = 0;
-            // every lane walks niter[j] taps: the walk must stay inside the frame's LDS work space
-            if (st + mt.niter[j] > kFrameFloats) {
+            // every lane walks niter[j] taps: the walk must stay inside the frame's LDS tile
+            if (kPGuard + 24 + st + mt.niter[j] > kFrameFloats) {
                 set_error("fbank512: mel pass %d too long", j);
                 return MMFE_EINVAL;
             }
@@ -324,8 +486,11 @@ int fbank512_prepare(Plan& plan) {
             for (int i = 0; i < len; ++i) mt.weights[(size_t)(mt.woff[j] + i) * 16 + l] = plan.band_weights[boff[m] + i];
         }
     }
+    std::vector<int32_t> niter(mt.niter, mt.niter + kMaxPass), woff(mt.woff, mt.woff + kMaxPass);
     if ((rc = upload(&plan.d_mel_start, mt.start))) return rc;
     if ((rc = upload(&plan.d_mel_w, mt.weights))) return rc;
+    if ((rc = upload(&plan.d_mel_niter, niter))) return rc;
+    if ((rc = upload(&plan.d_mel_woff, woff))) return rc;
     return MMFE_OK;
 }
 
@@ -348,9 +513,6 @@ int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
     a.hop = s.hop;
     a.win_len = s.win_len;
     a.n_mel = s.n_mel;
-    a.n_pass = plan.mel16.n_pass;
-    a.mel_rows = std::max(plan.mel16.total_rows, 1);
-    for (int j = 0; j < kMaxPass; ++j) { a.niter[j] = plan.mel16.niter[j]; a.woff[j] = plan.mel16.woff[j]; }
     a.preemph = s.preemph;
     a.remove_dc = s.remove_dc;
     a.inv_win_len = 1.0f / (float)s.win_len;
@@ -362,11 +524,18 @@ int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
     a.window = plan.d_window;
     a.tw_stage = reinterpret_cast<const float2*>(plan.d_tw_a);
     a.tw_post = reinterpret_cast<const float2*>(plan.d_tw_b);
+    a.n_pass = plan.mel16.n_pass;
+    a.mel_rows = std::max(plan.mel16.total_rows, 1);
     a.mel_start = plan.d_mel_start;
+    a.mel_niter = plan.d_mel_niter;
+    a.mel_woff = plan.d_mel_woff;
     a.mel_w = plan.d_mel_w;
+    a.mel4_kstart = plan.d_mel4_kstart;
+    a.mel4_w = plan.d_mel4_w;
 
-    const size_t lds = 256 * 8 + kTwPostEntries * 8 + 512 * 4 + kMaxPass * 16 * 4 + (size_t)a.mel_rows * 64 +
-                       (size_t)kWavesPerBlock * 4 * kFrameLds;
+    const bool mfma = plan.mel4_nga > 0;
+    const size_t tables = 256 * 8 + kTwPostEntries * 8 + 512 * 4 + (mfma ? 0 : kMaxPass * 16 * 4 + (size_t)a.mel_rows * 64);
+    const size_t lds = tables + (size_t)kWavesPerBlock * 4 * kFrameLds;
     if (lds > 160 * 1024) {
         set_error("fbank512: mel tap table does not fit in LDS (%zu bytes)", lds);
         return MMFE_EINVAL;
@@ -374,16 +543,32 @@ int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
     int dev = 0, cus = 256;
     MMFE_HIP_CHECK(hipGetDevice(&dev));
     MMFE_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int blocks_per_cu = std::max<int>(1, (int)((160 * 1024) / lds));
     const int64_t want = (quads + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int grid = (int)std::min<int64_t>(want, (int64_t)cus * 3);
+    const int by_waves = std::max(1, (4 * MMFE_FBANK_MIN_WAVES_PER_SIMD) / kWavesPerBlock);
+    const int grid = (int)std::min<int64_t>(want, (int64_t)cus * std::min(blocks_per_cu, by_waves));
 
     // 8-byte lane loads need every frame start to be 8-byte aligned
-    bool vec2 = (s.hop % 2 == 0) && (reinterpret_cast<uintptr_t>(src.base) % 8 == 0);
+    bool vec2 = (s.hop % 2 == 0) && (s.win_len % 2 == 0) && (reinterpret_cast<uintptr_t>(src.base) % 8 == 0);
     if (src.offsets == nullptr) vec2 = vec2 && (src.stride % 2 == 0);
     else vec2 = false;   // slice offsets are data: take the scalar-load variant
     const int na = (s.win_len + 31) / 32;
-    if (na <= 13) return vec2 ? launch_variant<13, true>(a, grid, lds, stream) : launch_variant<13, false>(a, grid, lds, stream);
-    return vec2 ? launch_variant<16, true>(a, grid, lds, stream) : launch_variant<16, false>(a, grid, lds, stream);
+    const int nga = plan.mel4_nga, ngb = plan.mel4_ngb;
+#define MMFE_FBANK_DISPATCH(NGA_, NGB_)                                                                         \
+    if (nga == NGA_ && ngb == NGB_) {                                                                           \
+        if (na == 13 && vec2) return launch_variant<13, true, true, NGA_, NGB_>(a, grid, lds, stream);          \
+        return vec2 ? launch_variant<16, true, false, NGA_, NGB_>(a, grid, lds, stream)                         \
+                    : launch_variant<16, false, false, NGA_, NGB_>(a, grid, lds, stream);                       \
+    }
+    MMFE_FBANK_DISPATCH(2, 7)
+    MMFE_FBANK_DISPATCH(3, 8)
+    MMFE_FBANK_DISPATCH(4, 0)
+    MMFE_FBANK_DISPATCH(8, 0)
+    MMFE_FBANK_DISPATCH(4, 8)
+    MMFE_FBANK_DISPATCH(0, 0)
+#undef MMFE_FBANK_DISPATCH
+    set_error("fbank512: no kernel variant for mel shape (%d, %d)", nga, ngb);
+    return MMFE_EINVAL;
 }
 
 }  // namespace mmfe

@@ -101,7 +101,8 @@ struct DeviceGuard {
 void free_plan(Plan* p) {
     if (p == nullptr) return;
     (void)hipFree(p->d_window); (void)hipFree(p->d_tw_a); (void)hipFree(p->d_tw_b); (void)hipFree(p->d_tw64); (void)hipFree(p->d_window64);
-    (void)hipFree(p->d_mel_start); (void)hipFree(p->d_mel_w);
+    (void)hipFree(p->d_mel_start); (void)hipFree(p->d_mel_w); (void)hipFree(p->d_mel_niter); (void)hipFree(p->d_mel_woff);
+    (void)hipFree(p->d_mel4_kstart); (void)hipFree(p->d_mel4_w);
     (void)hipFree(p->d_band_start); (void)hipFree(p->d_band_len); (void)hipFree(p->d_band_off); (void)hipFree(p->d_band_w);
     (void)hipFree(p->d_rowmax);
     delete p;

@@ -68,6 +68,11 @@ struct Plan {
     double* d_window64 = nullptr;     // float64 window (any-length DFT kernel)
     int32_t* d_mel_start = nullptr;
     float* d_mel_w = nullptr;
+    int32_t* d_mel_niter = nullptr;
+    int32_t* d_mel_woff = nullptr;
+    int mel4_nga = 0, mel4_ngb = 0;   // matrix-pipe mel form: groups of 4 bins per filter set (0 = not used)
+    int32_t* d_mel4_kstart = nullptr;
+    float* d_mel4_w = nullptr;
     int32_t* d_band_start = nullptr;  // plain CSR copy (generic DFT kernel)
     int32_t* d_band_len = nullptr;
     int32_t* d_band_off = nullptr;
