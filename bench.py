@@ -30,7 +30,7 @@ BYTES_PER_CLIP = 384 * 400 * 4 + OUT_FRAMES * N_MEL * 4          # 811008
 HBM_PEAK_GBS = 8000.0                                             # MI355X HBM3E peak
 
 
-def cpu_baseline(budget_s: float = 12.0, max_clips: int = 4096):
+def cpu_baseline(budget_s: float = 12.0, max_clips: int = 200000):
     """The CPU restatement of the reference's per-clip front-end (oracle, kind 'port'), driven the way
     the reference drives it: one clip per call, one thread (a DataLoader worker is one process)."""
     from oracle import frontend_oracle as O

@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 namespace mmfe {
@@ -43,11 +44,34 @@ constexpr int kPGuard = 8;                   // floats in front of the power spe
 #ifndef MMFE_FBANK_MIN_WAVES_PER_SIMD
 #define MMFE_FBANK_MIN_WAVES_PER_SIMD 3
 #endif
+#ifndef MMFE_PREFETCH_AT
+#define MMFE_PREFETCH_AT 1   // 0: after the first-half transpose write, 1: after the second-half spectrum write
+#endif
+#ifndef MMFE_TWIDDLE_REGS
+#define MMFE_TWIDDLE_REGS 1   // 1: first-half twiddles live in 30 VGPRs instead of LDS
+#endif
+#ifndef MMFE_MEL_ACC_A
+#define MMFE_MEL_ACC_A 1
+#endif
+#ifndef MMFE_MEL_ACC_B
+#define MMFE_MEL_ACC_B 1
+#endif
 constexpr int kWavesPerBlock = MMFE_FBANK_WAVES;
 constexpr int kTwPostEntries = 144;          // -i*W512^k for k = 0..143
 constexpr int kMaxPass = MelPassTable::kMaxPass;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct LogAffine {
+    float max_with;     // floor for the max kinds, -inf otherwise
+    float add_to;       // epsilon for the add kind, 0 otherwise
+    float mul;          // log-base change * out_scale
+    float add;          // out_shift * out_scale
+    float floor_cmp;    // floor for the max kinds, -inf otherwise
+    float floor_val;    // value of floored cells
+    float out_shift, out_scale;
+    float none_flag;    // 1 when there is no log at all
+};
 
 struct FbankArgs {
     RowSource src;
@@ -59,12 +83,8 @@ struct FbankArgs {
     int win_len;
     int n_mel;
     float preemph;
-    int remove_dc;
-    float inv_win_len;
-    int log_kind;
-    float log_floor;
-    float log_of_floor;
-    float out_shift, out_scale;
+    float mean_scale;          // 1/win_len when the per-frame mean is removed, else 0
+    LogAffine la;
     const float* window;       // 512 floats, pre-halved, zero beyond win_len
     const float2* tw_stage;    // 256: W256^n
     const float2* tw_post;     // 144: -i*W512^k
@@ -78,6 +98,7 @@ struct FbankArgs {
     // matrix-pipe mel form
     const int32_t* mel4_kstart;  // 2*64: first bin of the run of (set, lane)
     const float* mel4_w;         // (4*NGA + 4*NGB) * 64 weights, step-major
+    unsigned long long* stamps;  // diagnostic build only
 };
 
 // Loads the 2-sample slices (32a+2b, 32a+2b+1), a = 0..NA-1, of one frame.  Branch-free, so the
@@ -106,17 +127,36 @@ __device__ __forceinline__ void load_frame(float2 (&v)[NA], const float* fp, con
     }
 }
 
-// Branch-free log stage.  `log_of_floor` is log(floor) rounded on the host, so floored cells carry the
-// value the reference's CPU libm produces (device logf is within 1 ulp, not correctly rounded).
-__device__ __forceinline__ float apply_log(float x, int kind, float floor_, float log_of_floor) {
-    const bool is_add = kind == MMFE_LOG_LN_ADD;
-    const bool is_max = kind == MMFE_LOG_LN_MAX || kind == MMFE_LOG_LOG10_MAX;
-    const float arg = is_add ? x + floor_ : fmaxf(x, floor_);
-    float l = logf(arg);
-    if (kind == MMFE_LOG_LOG10_MAX) l *= 0.43429448190325182765f;
-    l = (is_max && x <= floor_) ? log_of_floor : l;
-    return kind == MMFE_LOG_NONE ? x : l;
+// Branch-free log + affine stage: result = (log(x) + out_shift) * out_scale, with the log taken by the
+// hardware base-2 logarithm (v_log_f32, about 1 ulp of log2) and the base change folded into one fma:
+//   result = log2(arg) * (ln2 * out_scale) + out_shift * out_scale.
+// Absolute error of the log is below 4e-6 over the range of spectra (|log| <= 30), far inside the
+// tolerance.  Floored cells (x <= floor) take `floor_val` = (log(floor) + out_shift) * out_scale computed
+// on the host from the host libm's log, the value the reference's CPU path produces.
+// The log kind is encoded as DATA (see make_log_affine), never as control flow: hipcc turns selects on
+// wave-uniform conditions into scalar branches, and a taken branch per value costs more than the log.
+__device__ __forceinline__ float apply_log_affine(float x, const LogAffine& L, float none_flag) {
+    const float arg = fmaxf(x, L.max_with) + L.add_to;            // max kinds: max(x, floor) + 0;  add kind: x + eps
+    float v = fmaf(__builtin_amdgcn_logf(arg), L.mul, L.add);
+    v = x <= L.floor_cmp ? L.floor_val : v;                       // floor_cmp = -inf unless a max kind
+    const float lin = (x + L.out_shift) * L.out_scale;
+    return none_flag != 0.f ? lin : v;                            // per-lane flag (kept opaque to the optimiser)
 }
+
+// Diagnostic build only (-DMMFE_STAMPS): per-phase s_memtime shares of the main loop, printed by the launcher.
+#ifdef MMFE_STAMPS
+#define MMFE_STAMP(i)                                                                                   \
+    do {                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        unsigned long long _t;                                                                          \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                      \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        if ((i) > 0) st_acc[(i) - 1] += _t - st_prev;                                                   \
+        st_prev = _t;                                                                                   \
+    } while (0)
+#else
+#define MMFE_STAMP(i) do { } while (0)
+#endif
 
 template <int NA /* ceil(win_len/32) */, bool VEC2, bool EXACT, int NGA, int NGB /* groups of 4 bins per mel set; NGA == 0: VALU mel */>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_SIMD) fbank512_kernel(const FbankArgs p) {
@@ -176,6 +216,13 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
     };
 
     const float* safe = row_ptr(p.src, 0);      // first samples of row 0: always readable
+#if MMFE_TWIDDLE_REGS
+    float2 twr[15];                             // W256^(b*c), c = 1..15: resident for the life of the kernel
+#pragma unroll
+    for (int c = 1; c < 16; ++c) twr[c - 1] = p.tw_stage[b * c];
+#endif
+    float none_flag = p.la.none_flag;
+    asm volatile("" : "+v"(none_flag));         // a per-lane value from here on: selects on it stay v_cndmask
     float2 nxt[NA];
     {
         const int t = (int)q * 4 + fl;
@@ -184,7 +231,11 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
         load_frame<NA, VEC2, EXACT>(nxt, fp, safe, valid, b, p.win_len);
     }
 
+#ifdef MMFE_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
+#endif
     while (row < (unsigned)p.n_rows) {
+        MMFE_STAMP(0);
         const int t0 = (int)q * 4;          // first frame of the quad
         const unsigned cur_row = row;
 
@@ -193,11 +244,11 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
         for (int a = 0; a < NA; ++a) g[a] = nxt[a];
 
         // ---- per-frame DC removal (kaldi remove_dc_offset) ------------------------------------
-        if (p.remove_dc) {
+        {
             float s = 0.f;
 #pragma unroll
             for (int a = 0; a < NA; ++a) s += g[a].x + g[a].y;
-            const float mean = row16_sum(s) * p.inv_win_len;
+            const float mean = row16_sum(s) * p.mean_scale;       // mean_scale = 0 switches the removal off
 #pragma unroll
             for (int a = 0; a < NA; ++a) { g[a].x -= mean; g[a].y -= mean; }
         }
@@ -225,39 +276,70 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
         }
 
         // ---- 256-point complex FFT, first half: 16-point FFT over a, twiddle, transpose --------
+        MMFE_STAMP(1);
         fft16(y);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             float2 val = y[fft16_pos(c)];
+#if MMFE_TWIDDLE_REGS
+            if (c > 0) val = cmul(val, twr[c - 1]);
+#else
             if (c > 0) val = cmul(val, s_tw_stage[b * c]);
+#endif
             fbuf[c * 17 + b] = val;
         }
         wave_lds_fence();
         // prefetch the next quad of this wave here, where register pressure is lowest (the first-half
         // registers are dead); the loads stay in flight under the second half of this iteration
+        MMFE_STAMP(2);
+#if MMFE_PREFETCH_AT == 0
         advance(row, q);
         {
             const int nt = (int)q * 4 + fl;
             const bool nvalid = row < (unsigned)p.n_rows && nt < p.frames_valid;
             const float* nfp = row_ptr(p.src, row < (unsigned)p.n_rows ? row : 0) + (int64_t)nt * p.hop;
+#ifdef MMFE_ABL_NOLOAD
+#pragma unroll
+            for (int a = 0; a < NA; ++a) nxt[a] = make_float2(nxt[a].y * 1.0001f, nxt[a].x + 1e-3f * (float)nt);
+#else
             load_frame<NA, VEC2, EXACT>(nxt, nfp, safe, nvalid, b, p.win_len);
+#endif
         }
+#endif
         float2 u[16];
 #pragma unroll
         for (int bb = 0; bb < 16; ++bb) u[bb] = fbuf[b * 17 + bb];
         wave_lds_fence();
 
         // ---- second half: lane c = b now owns Z[c + 16 d]; park Z in natural order --------------
+        MMFE_STAMP(3);
         fft16(u);
 #pragma unroll
         for (int d = 0; d < 16; ++d) fbuf[b + 16 * d] = u[fft16_pos(d)];
+        // bin 128 pairs with itself: X[128] = 2*conj(Z[128]) (window pre-halved), and Z[128] is lane 0's d = 8
+        const float p128 = 4.0f * (u[fft16_pos(8)].x * u[fft16_pos(8)].x + u[fft16_pos(8)].y * u[fft16_pos(8)].y);
         wave_lds_fence();
 
         // ---- real-FFT recombination on pairs (k, 256-k), power spectrum ------------------------
-        float pk[9], pq[9];
+#if MMFE_PREFETCH_AT == 1
+        advance(row, q);
+        {
+            const int nt = (int)q * 4 + fl;
+            const bool nvalid = row < (unsigned)p.n_rows && nt < p.frames_valid;
+            const float* nfp = row_ptr(p.src, row < (unsigned)p.n_rows ? row : 0) + (int64_t)nt * p.hop;
+#ifdef MMFE_ABL_NOLOAD
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int k = b + 16 * i;                   // i == 8 is only meaningful for b == 0 (k = 128)
+            for (int a = 0; a < NA; ++a) nxt[a] = make_float2(nxt[a].y * 1.0001f, nxt[a].x + 1e-3f * (float)nt);
+#else
+            load_frame<NA, VEC2, EXACT>(nxt, nfp, safe, nvalid, b, p.win_len);
+#endif
+        }
+#endif
+        MMFE_STAMP(4);
+        float pk[8], pq[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = b + 16 * i;
             const float2 zk = fbuf[k];
             const float2 zp = fbuf[(256 - k) & 255];
             const float2 tw = s_tw_post[k];
@@ -275,27 +357,47 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
             pbuf[k] = pk[i];
             pbuf[256 - k] = pq[i];
         }
-        pbuf[b == 0 ? 128 : 272 + b] = pk[8];      // only lane 0's ninth pair is bin 128; the others park theirs in unused slots
+        pbuf[b == 0 ? 128 : 272 + b] = p128;       // only lane 0 holds bin 128; the other lanes park their value in unused slots
         wave_lds_fence();
 
+        MMFE_STAMP(5);
         // ---- banded mel projection, log, affine, store ----------------------------------------
         if (kMfmaMel) {
-            f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+            // several independent accumulators per filter set: a dependent v_mfma chain pays the full MFMA
+            // latency per step, independent ones issue back to back; the partial sums are added at the end
+            constexpr int kAccA = MMFE_MEL_ACC_A, kAccB = MMFE_MEL_ACC_B;
+            f32x4 pa[kAccA], pb[kAccB];
 #pragma unroll
-            for (int s = 0; s < kStepsA; ++s) accA = __builtin_amdgcn_mfma_f32_4x4x1f32(pa_A[s], wreg[s], accA, 0, 0, 0);
+            for (int i = 0; i < kAccA; ++i) pa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < kStepsB; ++s) accB = __builtin_amdgcn_mfma_f32_4x4x1f32(pa_B[s], wreg[kStepsA + s], accB, 0, 0, 0);
+            for (int i = 0; i < kAccB; ++i) pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < kStepsA; ++s)
+                pa[s % kAccA] = __builtin_amdgcn_mfma_f32_4x4x1f32(pa_A[s], wreg[s], pa[s % kAccA], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < kStepsB; ++s)
+                pb[s % kAccB] = __builtin_amdgcn_mfma_f32_4x4x1f32(pa_B[s], wreg[kStepsA + s], pb[s % kAccB], 0, 0, 0);
+            f32x4 accA = pa[0], accB = pb[0];
+#pragma unroll
+            for (int i = 1; i < kAccA; ++i) accA += pa[i];
+#pragma unroll
+            for (int i = 1; i < kAccB; ++i) accB += pb[i];
             // lane holds filter (64*set + lane) of the quad's 4 frames in registers 0..3.  Frames past
             // the row's last frame repeat frame 0's store (same address, same value): no branch.
+            MMFE_STAMP(6);
             float va[4], vb[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                va[r] = (apply_log(accA[r], p.log_kind, p.log_floor, p.log_of_floor) + p.out_shift) * p.out_scale;
-                vb[r] = NGB > 0 ? (apply_log(accB[r], p.log_kind, p.log_floor, p.log_of_floor) + p.out_shift) * p.out_scale : 0.f;
+                va[r] = apply_log_affine(accA[r], p.la, none_flag);
+                vb[r] = NGB > 0 ? apply_log_affine(accB[r], p.la, none_flag) : 0.f;
             }
             const int n_ok = p.frames_valid - t0;         // >= 1, wave-uniform
             float* obase = p.out + ((int64_t)cur_row * p.out_rows + t0) * p.n_mel + lane;
+#ifdef MMFE_ABL_NOSTORE
+            if (lane < p.n_mel && va[0] == 123.456f && vb[1] == 654.321f) {
+#else
             if (lane < p.n_mel) {
+#endif
 #pragma unroll
                 for (int r = 0; r < 4; ++r) obase[r < n_ok ? r * p.n_mel : 0] = r < n_ok ? va[r] : va[0];
             }
@@ -314,13 +416,20 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
                 const int n = p.mel_niter[j];
                 float acc = 0.f;
                 for (int i = 0; i < n; ++i) acc = fmaf(wp[16 * i], pp[i], acc);
-                float val = apply_log(acc, p.log_kind, p.log_floor, p.log_of_floor);
-                val = (val + p.out_shift) * p.out_scale;
+                const float val = apply_log_affine(acc, p.la, none_flag);
                 if (valid && m < p.n_mel) orow[m] = val;
             }
         }
+        MMFE_STAMP(7);
+#ifdef MMFE_STAMPS
+        st_acc[7] += 1;
+#endif
         wave_lds_fence();
     }
+#ifdef MMFE_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) p.stamps[((size_t)blockIdx.x * kWavesPerBlock + wave) * 8 + i] = st_acc[i];
+#endif
 }
 
 template <int NA, bool VEC2, bool EXACT, int NGA, int NGB>
@@ -334,9 +443,31 @@ int launch_variant(const FbankArgs& args, int grid, size_t lds, hipStream_t stre
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         done_mask |= 1ull << (dev & 63);
     }
+#ifdef MMFE_STAMPS
+    FbankArgs targs = args;
+    const size_t n_st = (size_t)grid * kWavesPerBlock * 8;
+    MMFE_HIP_CHECK(hipMalloc((void**)&targs.stamps, n_st * 8));
+    MMFE_HIP_CHECK(hipMemset(targs.stamps, 0, n_st * 8));
+    hipLaunchKernelGGL((fbank512_kernel<NA, VEC2, EXACT, NGA, NGB>), dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, targs);
+    MMFE_HIP_CHECK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(n_st);
+    MMFE_HIP_CHECK(hipMemcpy(h.data(), targs.stamps, n_st * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(targs.stamps);
+    static int printed = 0;
+    if (printed++ < 2) {
+        double sum[8] = {0};
+        for (size_t w = 0; w < n_st / 8; ++w) for (int i = 0; i < 8; ++i) sum[i] += (double)h[w * 8 + i];
+        const char* names[7] = {"load+preproc", "fft1+twiddle+Twrite", "prefetch+Tread", "fft2+Zwrite", "pairs+Pwrite", "mel(mfma)", "log+store"};
+        double tot = 0; for (int i = 0; i < 7; ++i) tot += sum[i];
+        for (int i = 0; i < 7; ++i) fprintf(stderr, "[stamps] %-22s %8.1f ticks/iter  %5.1f%%\n", names[i], sum[i] / sum[7], 100.0 * sum[i] / tot);
+        fprintf(stderr, "[stamps] total %.1f ticks/iter, %.0f iterations\n", tot / sum[7], sum[7]);
+    }
+    return MMFE_OK;
+#else
     hipLaunchKernelGGL((fbank512_kernel<NA, VEC2, EXACT, NGA, NGB>), dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, args);
     MMFE_HIP_CHECK(hipGetLastError());
     return MMFE_OK;
+#endif
 }
 
 // Instantiated (NGA, NGB) shapes of the matrix-pipe mel form, smallest first.
@@ -443,11 +574,12 @@ int fbank512_prepare(Plan& plan) {
         }
     }
     // matrix-pipe mel form when the bank fits an instantiated shape (MMFE_MEL_FORM=valu forces the VALU form,
-    // MMFE_MEL_ALIGN=0 drops the bank-conflict-free run alignment)
+    // MMFE_MEL_ALIGN=1 starts every bin run at blk (mod 8), which makes the LDS operand reads bank-conflict-free
+    // at the price of longer runs; measured slower than the shorter unaligned runs, so it is off by default)
     const char* form = std::getenv("MMFE_MEL_FORM");
     const char* al = std::getenv("MMFE_MEL_ALIGN");
     const bool want_mfma = !(form != nullptr && std::string(form) == "valu");
-    const bool align = !(al != nullptr && std::string(al) == "0");
+    const bool align = al != nullptr && std::string(al) == "1";
     plan.mel4_nga = plan.mel4_ngb = 0;
     if (want_mfma && !build_mel4(plan, align) && align) (void)build_mel4(plan, false);
 
@@ -514,13 +646,21 @@ int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
     a.win_len = s.win_len;
     a.n_mel = s.n_mel;
     a.preemph = s.preemph;
-    a.remove_dc = s.remove_dc;
-    a.inv_win_len = 1.0f / (float)s.win_len;
-    a.log_kind = s.log_kind;
-    a.log_floor = s.log_floor;
-    a.log_of_floor = s.log_kind == MMFE_LOG_LOG10_MAX ? (float)std::log10((double)s.log_floor) : (float)std::log((double)s.log_floor);
-    a.out_shift = s.out_shift;
-    a.out_scale = s.out_scale;
+    a.mean_scale = s.remove_dc ? 1.0f / (float)s.win_len : 0.0f;
+    {
+        const bool is_max = s.log_kind == MMFE_LOG_LN_MAX || s.log_kind == MMFE_LOG_LOG10_MAX;
+        const double base = s.log_kind == MMFE_LOG_LOG10_MAX ? 0.30102999566398119521 : 0.69314718055994530942;   // log10(2), ln(2)
+        const float lof = s.log_kind == MMFE_LOG_LOG10_MAX ? (float)std::log10((double)s.log_floor) : (float)std::log((double)s.log_floor);
+        a.la.max_with = is_max ? s.log_floor : -INFINITY;
+        a.la.add_to = s.log_kind == MMFE_LOG_LN_ADD ? s.log_floor : 0.0f;
+        a.la.mul = (float)(base * (double)s.out_scale);
+        a.la.add = (float)((double)s.out_shift * (double)s.out_scale);
+        a.la.floor_cmp = is_max ? s.log_floor : -INFINITY;
+        a.la.floor_val = (lof + s.out_shift) * s.out_scale;
+        a.la.out_shift = s.out_shift;
+        a.la.out_scale = s.out_scale;
+        a.la.none_flag = s.log_kind == MMFE_LOG_NONE ? 1.0f : 0.0f;
+    }
     a.window = plan.d_window;
     a.tw_stage = reinterpret_cast<const float2*>(plan.d_tw_a);
     a.tw_post = reinterpret_cast<const float2*>(plan.d_tw_b);

@@ -86,9 +86,11 @@ __device__ __forceinline__ float row16_sum(float s) {
 // Orders LDS traffic between the lanes of one wave (no instruction is emitted for it beyond what
 // the memory model requires: a wave's DS operations already execute in program order).
 __device__ __forceinline__ void wave_lds_fence() {
+#ifndef MMFE_NO_WAVE_FENCE
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
 }
 
 }  // namespace mmfe
