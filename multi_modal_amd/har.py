@@ -35,6 +35,10 @@ def stft_mag(x, fs: float = 100, nperseg: int = 32, noverlap: int = 28, out: Opt
     tensor in -> tensor out on the tensor's device."""
     is_np = isinstance(x, np.ndarray)
     t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)) if is_np else x
+    if t.shape[-1] < nperseg:
+        # scipy shrinks nperseg to the input length in this case (a different transform); the reference's IMU
+        # windows are always longer, so it is rejected rather than silently computed with nperseg taps
+        raise ValueError(f"input length {t.shape[-1]} is shorter than nperseg {nperseg}")
     lead = tuple(t.shape[:-1])
     rows = t.reshape(-1, t.shape[-1])
     d, origin = to_device_rows(rows)

@@ -34,9 +34,14 @@ def kaldi_window(window_type: str, size: int, blackman_coeff: float = 0.42) -> n
 
 
 def periodic_hann(size: int) -> np.ndarray:
-    """scipy.signal.get_window('hann', size, fftbins=True) evaluated in fp64."""
-    j = np.arange(size, dtype=np.float64)
-    return 0.5 - 0.5 * np.cos(2.0 * np.pi * j / size)
+    """scipy.signal.get_window('hann', size, fftbins=True), bit for bit: scipy evaluates the symmetric
+    size+1 point generalised cosine 0.5*cos(0*t) + 0.5*cos(1*t) on t = linspace(-pi, pi, size+1) and drops
+    the last point (librosa.stft and scipy.signal.stft both take their window from there)."""
+    t = np.linspace(-np.pi, np.pi, size + 1)
+    w = np.zeros(size + 1)
+    for k, a in enumerate((0.5, 0.5)):
+        w += a * np.cos(k * t)
+    return w[:-1]
 
 
 def kaldi_mel_banks(num_bins: int, padded_window: int, sample_freq: float, low_freq: float = 20.0,

@@ -36,6 +36,7 @@ from __future__ import annotations
 import math
 
 import numpy as np
+import scipy.signal
 import torch
 
 # --------------------------------------------------------------------------------------
@@ -153,8 +154,7 @@ def centred_stft(y: np.ndarray, n_fft: int, hop_length: int, win_length: int, pa
     around its centre, signal padded by n_fft//2 both sides, frames multiplied in fp64,
     rfft in fp64, result stored complex64, layout (1 + n_fft//2, n_frames)."""
     y = np.asarray(y, dtype=np.float32)
-    j = np.arange(win_length, dtype=np.float64)
-    w = 0.5 - 0.5 * np.cos(2.0 * np.pi * j / win_length)
+    w = scipy.signal.get_window("hann", win_length, fftbins=True)      # what librosa.filters.get_window returns (fp64)
     lpad = (n_fft - win_length) // 2
     w = np.pad(w, (lpad, n_fft - win_length - lpad))
     yp = np.pad(y, n_fft // 2, mode=pad_mode)
@@ -206,9 +206,12 @@ def stft_mag(x: np.ndarray, fs: float = 100, nperseg: int = 32, noverlap: int = 
     scaling='spectrum', one-sided; fp64 arithmetic on fp32 input, window rounded to fp32,
     result rounded to complex64, magnitude taken in fp32.  (..., T) -> (..., nperseg/2+1, S)."""
     x = np.asarray(x)
+    if x.shape[-1] < nperseg:
+        # scipy silently shrinks nperseg to the input length here (and then fails when noverlap >= nperseg);
+        # the IMU windows of the reference are always longer, so this case is rejected, not imitated
+        raise ValueError(f"input length {x.shape[-1]} is shorter than nperseg {nperseg}")
     hop = nperseg - noverlap
-    j = np.arange(nperseg, dtype=np.float64)
-    win = (0.5 - 0.5 * np.cos(2.0 * np.pi * j / nperseg))
+    win = scipy.signal.get_window("hann", nperseg)                      # scipy.signal.stft's default window (periodic, fp64)
     scale = 1.0 / win.sum()                       # sqrt(1/sum^2), 'spectrum' scaling
     win32 = win.astype(np.float32).astype(np.float64)
     half = nperseg // 2
@@ -278,8 +281,7 @@ def whisper_logmel(wave: np.ndarray, n_fft: int = 400, hop: int = 160, n_mels: i
     log10(max(., 1e-10)), last frame dropped, clamp to (max - 8), (x + 4) / 4.  fp64 maths,
     fp32 result."""
     y = np.asarray(wave, dtype=np.float64)
-    j = np.arange(n_fft, dtype=np.float64)
-    w = 0.5 - 0.5 * np.cos(2.0 * np.pi * j / n_fft)
+    w = scipy.signal.get_window("hann", n_fft, fftbins=True)
     yp = np.pad(y, n_fft // 2, mode="reflect")
     n_frames = 1 + (yp.shape[0] - n_fft) // hop
     idx = hop * np.arange(n_frames)[:, None] + np.arange(n_fft)[None, :]

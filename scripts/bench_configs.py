@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Throughput of the secondary configurations (BASELINE.json configs[2], the EPIC parity configuration and
+configs[4] per GPU) on one GPU: units/s, achieved algorithmic GB/s and fraction of the 8 TB/s HBM peak.
+
+    python scripts/bench_configs.py [har] [epic] [logmel] [--iters 20]
+"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import multi_modal_amd as mm  # noqa: E402
+
+
+def timeit(fn, iters, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for s, e in ev:
+        s.record()
+        fn()
+        e.record()
+    torch.cuda.synchronize()
+    ms = sorted(s.elapsed_time(e) for s, e in ev)
+    return sum(ms) / len(ms), ms[0]
+
+
+def main():
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["har", "epic", "logmel"]
+    iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 20
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(4321)
+    if "har" in which:
+        B = 262144
+        x = torch.randn(B, 6, 192, device=dev, generator=g)
+        out = torch.empty(B, 6, 17, 49, device=dev)
+        avg, mn = timeit(lambda: mm.stft_mag(x, out=out), iters)
+        per = 6 * 192 * 4 + 6 * 17 * 49 * 4
+        print(json.dumps({"config": "HAR (262144, 6, 192) -> (262144, 6, 17, 49)", "windows_per_s": B / (avg * 1e-3), "ms": avg, "min_ms": mn,
+                          "bytes_per_window": per, "GB/s": per * B / (avg * 1e-3) / 1e9, "frac_of_8TBs": per * B / (avg * 1e-3) / 8e12}))
+        del x, out
+    if "epic" in which:
+        B = 4096
+        x = (0.1 * torch.randn(B, 30672, device=dev, generator=g)).clamp_(-1, 1)
+        out = torch.empty(B, 256, 256, device=dev)
+        avg, mn = timeit(lambda: mm.log_specgram_batch(x, div255=True, out=out), iters)
+        per = 30672 * 4 + 256 * 256 * 4
+        print(json.dumps({"config": "EPIC (4096, 30672) -> (4096, 256, 256), n_fft 511", "clips_per_s": B / (avg * 1e-3), "ms": avg, "min_ms": mn,
+                          "bytes_per_clip": per, "GB/s": per * B / (avg * 1e-3) / 1e9, "frac_of_8TBs": per * B / (avg * 1e-3) / 8e12}))
+        del x, out
+    if "logmel" in which:
+        B = 256
+        x = (0.1 * torch.randn(B, 480000, device=dev, generator=g)).clamp_(-1, 1)
+        out = torch.empty(B, 80, 3000, device=dev)
+        avg, mn = timeit(lambda: mm.logmel.log_mel_spectrogram(x, out=out), max(3, iters // 4))
+        per = 480000 * 4 + 80 * 3000 * 4
+        print(json.dumps({"config": "long-utterance log-mel (256, 480000) -> (256, 80, 3000), n_fft 400", "utt_per_s": B / (avg * 1e-3), "ms": avg,
+                          "min_ms": mn, "bytes_per_utt": per, "GB/s": per * B / (avg * 1e-3) / 1e9, "frac_of_8TBs": per * B / (avg * 1e-3) / 8e12}))
+
+
+if __name__ == "__main__":
+    main()

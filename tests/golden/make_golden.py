@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ (run HERE, in the build container; the files travel,
+/root/reference and third-party sources do not).
+
+What pins what
+  har_stft.npz        outputs of scipy.signal.stft itself, the third-party function the reference calls at
+                      classification/har/adbox.py:20 with the literal arguments used there  -> PINNED
+  frame_signal.npz    outputs of the reference's own frame_signal
+                      (classification/vggsound/utils/transforms.py:19-61), executed from the reference file:
+                      the function definition alone is compiled from the file's AST, because importing the
+                      whole module needs torchvision, which this image does not have  -> PINNED
+  kaldi_fbank.npz     outputs of the oracle's restatement (torchaudio is absent: PARITY UNPINNED) plus the
+                      same cells computed by an independent float64 implementation that is present in the
+                      image (transformers.audio_utils.spectrogram with kaldi mel scale, the recipe
+                      transformers uses as its torchaudio-free fallback) as a cross-check
+  epic_logspec.npz    outputs of the oracle's restatement (librosa is absent: PARITY UNPINNED) plus a plain
+                      numpy.fft.rfft evaluation on explicitly framed data as a cross-check
+  logmel.npz          long-utterance log-mel (not in the reference): oracle restatement vs
+                      transformers.WhisperFeatureExtractor
+Inputs are regenerated from tests/conftest.synth (integer PRNG), so no waveform is stored.
+"""
+import ast
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from conftest import synth  # noqa: E402
+from oracle import frontend_oracle as O  # noqa: E402
+
+REF = "/root/reference"
+KINDS = ["noise0.1", "uniform", "sine+noise", "silence", "impulse", "dc", "quiet"]
+FRAMES = [0, 1, 191, 383]          # first / second / middle / last kept frame of the 384
+
+
+def har():
+    import scipy.signal
+    out = {}
+    for name, shape, seed in [("b6x192", (4, 6, 192), 4321), ("c15x1003", (15, 1003), 7), ("exact32", (2, 32), 9), ("t33", (3, 33), 11)]:
+        rng = np.random.default_rng(seed)
+        x = (rng.integers(-(1 << 20), 1 << 20, size=shape).astype(np.float64) / float(1 << 18)).astype(np.float32)
+        y = np.abs(scipy.signal.stft(x, fs=100, nperseg=32, noverlap=28)[-1])
+        out[name + "_x"] = x
+        out[name + "_y"] = y.astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "har_stft.npz"), **out)
+    print("har_stft.npz", {k: v.shape for k, v in out.items()})
+
+
+def frame_signal():
+    src = open(os.path.join(REF, "classification/vggsound/utils/transforms.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "frame_signal"][0]
+    ns = {"torch": torch, "math": math}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "reference:frame_signal", "exec"), ns)
+    ref_fn = ns["frame_signal"]
+    out = {}
+    cases = [((1, 10), 4, 3), ((2, 1600), 400, 160), ((3,), 8, 2), ((2, 3, 100), 16, 7), ((5,), 5, 2), ((7,), 5, 3), ((1, 33), 32, 4)]
+    for i, (shape, fl, hop) in enumerate(cases):
+        rng = np.random.default_rng(100 + i)
+        s = (rng.integers(-1000, 1000, size=shape).astype(np.float32) / 256.0)
+        w = (rng.integers(-1000, 1000, size=fl).astype(np.float32) / 512.0)
+        y = ref_fn(torch.from_numpy(s), fl, hop, torch.from_numpy(w)).numpy()
+        y1 = ref_fn(torch.from_numpy(s), fl, hop).numpy()
+        out[f"c{i}_signal"], out[f"c{i}_window"] = s, w
+        out[f"c{i}_params"] = np.array([fl, hop])
+        out[f"c{i}_out"], out[f"c{i}_out_ones"] = y, y1
+    np.savez_compressed(os.path.join(HERE, "frame_signal.npz"), **out)
+    print("frame_signal.npz", len(cases), "cases")
+
+
+def kaldi():
+    from transformers.audio_utils import mel_filter_bank, spectrogram, window_function
+    import warnings
+    warnings.simplefilter("ignore")
+    mf = mel_filter_bank(257, 128, 20, 8000, 16000, norm=None, mel_scale="kaldi", triangularize_in_mel_space=True)
+    win = window_function(400, "hann", periodic=False)
+    out = {"frames": np.array(FRAMES)}
+    for i, kind in enumerate(KINDS):
+        x = synth(kind, 160000, 1234 + i)
+        raw = O.kaldi_fbank(torch.from_numpy(x)[None], sample_frequency=16000, window_type="hanning", num_mel_bins=128, frame_shift=25).numpy()
+        norm = O.preprocessing_audio(torch.from_numpy(x)[None]).numpy()
+        hf = spectrogram(x.astype(np.float64), win, frame_length=400, hop_length=400, fft_length=512, power=2.0, center=False,
+                         preemphasis=0.97, mel_filters=mf, log_mel="log", mel_floor=1.192092955078125e-07,
+                         remove_dc_offset=True, dtype=np.float64).T
+        assert raw.shape == (400, 128) and norm.shape == (384, 128) and hf.shape == (400, 128)
+        out[f"{kind}_raw"] = raw[FRAMES].astype(np.float32)
+        out[f"{kind}_norm"] = norm[FRAMES].astype(np.float32)
+        out[f"{kind}_hf64"] = hf[FRAMES].astype(np.float64)
+        out[f"{kind}_sums"] = np.array([raw.astype(np.float64).sum(), (raw.astype(np.float64) ** 2).sum(),
+                                        norm.astype(np.float64).sum(), (norm.astype(np.float64) ** 2).sum()])
+    bank = torch.nn.functional.pad(O.kaldi_mel_banks(128, 512, 16000.0), (0, 1)).numpy()
+    out["bank_nnz_per_row"] = (bank > 0).sum(1).astype(np.int32)
+    out["bank_first_rows"] = bank[:8, :8].astype(np.float32)
+    out["bank_checksum"] = np.array([bank.astype(np.float64).sum(), (bank.astype(np.float64) ** 2).sum()])
+    np.savez_compressed(os.path.join(HERE, "kaldi_fbank.npz"), **out)
+    print("kaldi_fbank.npz", len(out), "arrays")
+
+
+def epic():
+    out = {}
+    rows = [0, 1, 17, 128, 255]
+    for n in (30672, 30696):
+        for kind in ("noise0.1", "quiet", "silence", "sine+noise"):
+            x = synth(kind, n, 4242 + n)
+            y = O.log_specgram(x)
+            assert y.shape == (256, 256) and y.dtype == np.float32
+            # independent evaluation: explicit framing + numpy rfft of length 511, float64 throughout
+            w = np.zeros(511)
+            w[135:375] = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(240) / 240)
+            xp = np.pad(x.astype(np.float64), 255)
+            fr = np.stack([xp[120 * t:120 * t + 511] * w for t in range(256)])
+            z = np.fft.rfft(fr, n=511, axis=1).T
+            chk = np.log(np.abs(z) ** 2 + 1e-6)
+            out[f"{kind}_{n}_rows"] = y[rows].astype(np.float32)
+            out[f"{kind}_{n}_cols"] = y[:, [0, 1, 128, 255]].astype(np.float32)
+            out[f"{kind}_{n}_np64_rows"] = chk[rows]
+            out[f"{kind}_{n}_sums"] = np.array([y.astype(np.float64).sum(), (y.astype(np.float64) ** 2).sum()])
+    out["rows"] = np.array(rows)
+    np.savez_compressed(os.path.join(HERE, "epic_logspec.npz"), **out)
+    print("epic_logspec.npz", len(out), "arrays")
+
+
+def logmel():
+    from transformers import WhisperFeatureExtractor
+    fe = WhisperFeatureExtractor()
+    x = synth("noise0.1", 480000, 99)
+    ref = fe._np_extract_fbank_features(x[None], "cpu")[0]
+    got = O.whisper_logmel(x)
+    assert ref.shape == got.shape == (80, 3000)
+    np.savez_compressed(os.path.join(HERE, "logmel.npz"), cols=np.array([0, 1, 1500, 2999]), hf=ref[:, [0, 1, 1500, 2999]].astype(np.float32),
+                        oracle=got[:, [0, 1, 1500, 2999]], sums=np.array([got.astype(np.float64).sum(), (got.astype(np.float64) ** 2).sum()]))
+    print("logmel.npz max|oracle-hf| =", float(np.abs(ref - got).max()))
+
+
+if __name__ == "__main__":
+    har()
+    frame_signal()
+    kaldi()
+    epic()
+    logmel()

@@ -171,7 +171,50 @@ def test_epic_batch_div255_and_slices(mm, O):
         assert np.abs(got[i] - ref).max() <= 1e-4 / 255 + 1e-7
 
 
-@pytest.mark.parametrize("shape", [(6, 192), (15, 1003), (3, 2, 64), (1, 31), (2, 4), (5, 33)])
+def test_har_short_input_rejected(mm):
+    for shape in [(1, 31), (2, 4)]:
+        with pytest.raises(ValueError):
+            mm.stft_mag(np.zeros(shape, np.float32))
+
+
+def test_har_golden_scipy(mm, golden_dir):
+    """Against stored outputs of scipy.signal.stft itself (the call at adbox.py:20)."""
+    g = np.load(f"{golden_dir}/har_stft.npz")
+    for name in ("b6x192", "c15x1003", "exact32", "t33"):
+        got = mm.stft_mag(g[name + "_x"])
+        assert got.shape == g[name + "_y"].shape
+        assert np.abs(got - g[name + "_y"]).max() <= 1e-6 * max(1.0, float(np.abs(g[name + "_y"]).max()))
+
+
+def test_frame_signal_golden_reference(mm, golden_dir):
+    """Against stored outputs of the reference's own frame_signal: bit exact."""
+    g = np.load(f"{golden_dir}/frame_signal.npz")
+    i = 0
+    while f"c{i}_signal" in g:
+        fl, hop = (int(v) for v in g[f"c{i}_params"])
+        s, w = torch.from_numpy(g[f"c{i}_signal"]), torch.from_numpy(g[f"c{i}_window"])
+        assert np.array_equal(mm.frame_signal(s.cuda(), fl, hop, w.cuda()).cpu().numpy(), g[f"c{i}_out"])
+        assert np.array_equal(mm.frame_signal(s, fl, hop).numpy(), g[f"c{i}_out_ones"])
+        i += 1
+    assert i == 7
+
+
+def test_kaldi_golden_cells(mm, golden_dir):
+    """Stored oracle cells (frames 0, 1, 191, 383) and the independent float64 cross-check."""
+    g = np.load(f"{golden_dir}/kaldi_fbank.npz")
+    frames = g["frames"]
+    for i, kind in enumerate(KINDS):
+        x = torch.from_numpy(synth(kind, 160000, 1234 + i))[None].cuda()
+        norm = mm.preprocessing_audio(x).cpu().numpy()
+        assert np.abs(norm[frames] - g[f"{kind}_norm"]).max() <= (5e-4 if kind not in HIGH_DYNAMIC_RANGE else 1e-3)
+        raw = mm.fbank(x, sample_frequency=16000, window_type="hanning", num_mel_bins=128, frame_shift=25).cpu().numpy()
+        d = np.abs(raw[frames] - g[f"{kind}_hf64"])
+        assert np.percentile(d, 99) <= 1e-3 and np.median(d) <= 2e-5      # independent fp64 implementation, fp64-built weights
+        s = g[f"{kind}_sums"]
+        assert abs(norm.astype(np.float64).sum() - s[2]) <= 1e-5 * 384 * 128 * 4
+
+
+@pytest.mark.parametrize("shape", [(6, 192), (15, 1003), (3, 2, 64), (2, 32), (5, 33)])
 def test_har_stft_mag(mm, O, shape):
     rng = np.random.default_rng(4321)
     x = rng.standard_normal(shape).astype(np.float32)
