@@ -15,13 +15,14 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace mmfe {
 
 namespace {
 
-constexpr int kThreads = 256;
 constexpr int kN = 32;
+constexpr int kMaxThreads = 1024;
 
 struct StftArgs {
     RowSource src;
@@ -33,6 +34,8 @@ struct StftArgs {
     int rows_per_block;  // R
     int row_lds;         // floats of LDS per staged row (16 + n_samples + tail, multiple of 4)
     int power;           // 1 = magnitude, 2 = power
+    int vec_in;          // rows are contiguous, 16-byte aligned and n_samples % 4 == 0: stage with 16-byte loads
+    int vec_out;         // every group's output block starts 16-byte aligned: drain with 16-byte stores
     float win[kN];       // window pre-multiplied by 0.5 * spec_scale
 };
 
@@ -43,41 +46,72 @@ __device__ __forceinline__ float2 tw32(int k) {
     return make_float2(-S[k], -S[8 - k]);
 }
 
-__global__ void __launch_bounds__(kThreads) stft32_kernel(const StftArgs p) {
+// One group = R consecutive rows.  Three phases separated by block barriers:
+//   stage  coalesced global reads -> LDS rows with zero margins (scipy's zero boundary extension + padding)
+//   work   one lane per frame: eight 16-byte LDS reads, 32-point real FFT in registers, 17 magnitudes
+//          written to an LDS image of the group's output block, laid out exactly like global memory
+//   drain  the output block is contiguous in global memory: 16-byte coalesced stores
+template <bool ALIGNED_HOP>
+__global__ void __launch_bounds__(kMaxThreads) stft32_kernel(const StftArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* s_in = reinterpret_cast<float*>(smem);
-
     const int R = p.rows_per_block;
     const int S = p.n_frames;
     const int T = p.n_samples;
+    float* s_in = reinterpret_cast<float*>(smem);                    // R * row_lds
+    float* s_out = s_in + R * p.row_lds;                             // R * 17 * S
     const int n_groups = (p.n_rows + R - 1) / R;
+    const int nthr = blockDim.x;
 
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int row0 = grp * R;
         const int rows = min(R, p.n_rows - row0);
-        __syncthreads();   // previous group's readers are done with s_in
-        // stage: zero margins + samples
-        for (int i = threadIdx.x; i < rows * p.row_lds; i += kThreads) {
-            const int r = i / p.row_lds;
-            const int j = i - r * p.row_lds - 16;          // sample index
-            float v = 0.f;
-            if (j >= 0 && j < T) v = row_ptr(p.src, row0 + r)[j];
-            s_in[i] = v;
+        __syncthreads();   // the previous group's drain is done with s_out, its workers with s_in
+        // ---- stage ----------------------------------------------------------------------------------
+        for (int i = threadIdx.x; i < rows * (p.row_lds - T); i += nthr) {          // zero margins
+            const int r = i / (p.row_lds - T);
+            int j = i - r * (p.row_lds - T);
+            j = j < 16 ? j : j + T;
+            s_in[r * p.row_lds + j] = 0.f;
+        }
+        if (p.vec_in) {
+            const float4* g4 = reinterpret_cast<const float4*>(p.src.base + (int64_t)row0 * T);
+            const int T4 = T >> 2;
+            for (int i = threadIdx.x; i < rows * T4; i += nthr) {
+                const int r = i / T4;
+                const int j4 = i - r * T4;
+                const float4 v = g4[i];
+                *reinterpret_cast<float4*>(s_in + r * p.row_lds + 16 + 4 * j4) = v;
+            }
+        } else {
+            for (int i = threadIdx.x; i < rows * T; i += nthr) {
+                const int r = i / T;
+                const int j = i - r * T;
+                s_in[r * p.row_lds + 16 + j] = row_ptr(p.src, row0 + r)[j];
+            }
         }
         __syncthreads();
-
+        // ---- work: one frame per lane ---------------------------------------------------------------
         const int n_fr = rows * S;
-        for (int f = threadIdx.x; f < n_fr; f += kThreads) {
+        for (int f = threadIdx.x; f < n_fr; f += nthr) {
             const int r = f / S;
             const int s = f - r * S;
             const float* xp = s_in + r * p.row_lds + s * p.hop;    // frame s covers samples [s*hop-16, s*hop+16)
+            float x[32];
+            if (ALIGNED_HOP) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(xp + 4 * q);
+                    x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int n = 0; n < 32; ++n) x[n] = xp[n];
+            }
             float2 z[16];
 #pragma unroll
-            for (int n = 0; n < 16; ++n) {
-                z[n] = make_float2(xp[2 * n] * p.win[2 * n], xp[2 * n + 1] * p.win[2 * n + 1]);
-            }
+            for (int n = 0; n < 16; ++n) z[n] = make_float2(x[2 * n] * p.win[2 * n], x[2 * n + 1] * p.win[2 * n + 1]);
             fft16(z);
-            float* o = p.out + ((int64_t)(row0 + r) * 17) * S + s;
+            float* o = s_out + r * 17 * S + s;
 #pragma unroll
             for (int k = 0; k <= 8; ++k) {
                 const float2 zk = z[fft16_pos(k)];
@@ -89,10 +123,23 @@ __global__ void __launch_bounds__(kThreads) stft32_kernel(const StftArgs p) {
                 const float2 xa = cadd(E, G), xb = csub(E, G);
                 float pa = xa.x * xa.x + xa.y * xa.y;
                 float pb = xb.x * xb.x + xb.y * xb.y;
-                if (p.power == 1) { pa = sqrtf(pa); pb = sqrtf(pb); }
-                o[(int64_t)k * S] = pa;
-                if (k != 8) o[(int64_t)(16 - k) * S] = pb;
+                if (p.power == 1) { pa = __builtin_amdgcn_sqrtf(pa); pb = __builtin_amdgcn_sqrtf(pb); }
+                o[k * S] = pa;
+                if (k != 8) o[(16 - k) * S] = pb;
             }
+        }
+        __syncthreads();
+        // ---- drain ----------------------------------------------------------------------------------
+        const int n_out = rows * 17 * S;
+        float* gout = p.out + (int64_t)row0 * 17 * S;
+        if (p.vec_out) {
+            const int n4 = n_out >> 2;
+            float4* g4 = reinterpret_cast<float4*>(gout);
+            const float4* l4 = reinterpret_cast<const float4*>(s_out);
+            for (int i = threadIdx.x; i < n4; i += nthr) g4[i] = l4[i];
+            for (int i = 4 * n4 + threadIdx.x; i < n_out; i += nthr) gout[i] = s_out[i];
+        } else {
+            for (int i = threadIdx.x; i < n_out; i += nthr) gout[i] = s_out[i];
         }
     }
 }
@@ -130,27 +177,53 @@ int stft32_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
     // LDS row: 16 leading zeros + samples + zeros up to the end of the last frame
     const int need = (int)((n_frames - 1) * s.hop + kN);
     a.row_lds = (std::max(need, (int)n_samples + 16) + 3) & ~3;
-    // rows per block: fill the 256 threads well without exceeding ~48 KB of LDS
-    const int max_rows = std::max(1, std::min<int>(64, (48 * 1024) / (a.row_lds * 4)));
-    int best_r = 1;
-    double best_eff = 0.0;
-    for (int r = 1; r <= max_rows; ++r) {
-        const double fr = (double)r * (double)n_frames;
-        const double eff = fr / (std::ceil(fr / kThreads) * kThreads);
-        if (eff > best_eff + 1e-9) { best_eff = eff; best_r = r; }
+    // rows per group R (a multiple of 4 keeps every group's output block 16-byte aligned) and block size:
+    // one lane per frame, pick the R that wastes the fewest lanes while 2+ blocks still fit in a CU's LDS
+    const int64_t per_row_bytes = ((int64_t)a.row_lds + 17 * n_frames) * 4;
+    int best_r = 0, best_threads = 0;
+    double best_eff = -1.0;
+    for (int r = 4; r <= 64; r += 4) {
+        if (r * per_row_bytes > 100 * 1024) break;
+        const int64_t fr = (int64_t)r * n_frames;
+        const int64_t thr = std::min<int64_t>(kMaxThreads, (fr + 63) / 64 * 64);
+        const double eff = (double)fr / (double)((fr + thr - 1) / thr * thr);
+        if (eff > best_eff + 0.005) { best_eff = eff; best_r = r; best_threads = (int)thr; }
+    }
+    if (const char* force = std::getenv("MMFE_STFT_ROWS")) {   // tuning override: rows per group
+        const int r = std::atoi(force);
+        if (r >= 4 && r % 4 == 0 && r * per_row_bytes <= 150 * 1024) {
+            best_r = r;
+            best_threads = (int)std::min<int64_t>(kMaxThreads, ((int64_t)r * n_frames + 63) / 64 * 64);
+        }
+    }
+    if (best_r == 0) {   // very long rows: one row per group, frames looped over the block
+        best_r = 1;
+        best_threads = 256;
+        if (per_row_bytes > 150 * 1024) {
+            set_error("stft32: a row of %lld samples does not fit the LDS staging buffers", (long long)n_samples);
+            return MMFE_EINVAL;
+        }
     }
     a.rows_per_block = best_r;
-    const size_t lds = (size_t)a.rows_per_block * a.row_lds * 4;
-    if (lds > 64 * 1024) {
-        set_error("stft32: a row of %lld samples does not fit the LDS staging buffer", (long long)n_samples);
-        return MMFE_EINVAL;
-    }
+    a.vec_in = (src.offsets == nullptr && src.stride == n_samples && n_samples % 4 == 0 &&
+                reinterpret_cast<uintptr_t>(src.base) % 16 == 0) ? 1 : 0;
+    a.vec_out = (((int64_t)best_r * 17 * n_frames) % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 1 : 0;
+    const size_t lds = (size_t)best_r * per_row_bytes;
     int dev = 0, cus = 256;
     MMFE_HIP_CHECK(hipGetDevice(&dev));
     MMFE_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int64_t groups = (n_rows + a.rows_per_block - 1) / a.rows_per_block;
-    const int grid = (int)std::min<int64_t>(groups, (int64_t)cus * 8);
-    hipLaunchKernelGGL(stft32_kernel, dim3(grid), dim3(kThreads), lds, stream, a);
+    const int64_t groups = (n_rows + best_r - 1) / best_r;
+    const int blocks_per_cu = std::max(1, std::min<int>((int)((160 * 1024) / lds), 2048 / best_threads));
+    const int grid = (int)std::min<int64_t>(groups, (int64_t)cus * blocks_per_cu);
+    const bool aligned_hop = s.hop % 4 == 0;
+    static unsigned long long done_mask[2] = {0, 0};
+    const void* fn = aligned_hop ? reinterpret_cast<const void*>(&stft32_kernel<true>) : reinterpret_cast<const void*>(&stft32_kernel<false>);
+    if (!(done_mask[aligned_hop] >> (dev & 63) & 1ull)) {
+        MMFE_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        done_mask[aligned_hop] |= 1ull << (dev & 63);
+    }
+    if (aligned_hop) hipLaunchKernelGGL(stft32_kernel<true>, dim3(grid), dim3(best_threads), lds, stream, a);
+    else hipLaunchKernelGGL(stft32_kernel<false>, dim3(grid), dim3(best_threads), lds, stream, a);
     MMFE_HIP_CHECK(hipGetLastError());
     return MMFE_OK;
 }
