@@ -8,8 +8,9 @@
 // Mapping: one lane owns one frame.  A block stages a group of consecutive rows in LDS with zero
 // margins (coalesced 16-byte global reads), every lane pulls its 32 samples with eight 16-byte LDS
 // reads, runs the 32-point real FFT as a 16-point complex FFT plus recombination entirely in
-// registers, and stores 17 magnitudes.  Lanes of a wave hold consecutive frames of a row, so each
-// of the 17 stores of a wave covers contiguous runs of the (row, bin, frame) output.
+// registers, and writes its 17 magnitudes into an LDS image of the group's output block.  That
+// block is contiguous in global memory, so it is drained with 16-byte coalesced stores: the kernel
+// is bound by HBM writes (81 % of its traffic), and partial-line stores would waste them.
 #include "mmfe_internal.h"
 #include "fft_regs.h"
 

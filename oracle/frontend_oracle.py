@@ -23,10 +23,10 @@ order those libraries use:
   numpy.fft.rfft on explicitly framed data.
 * stft_mag -> numpy.abs(scipy.signal.stft(...)[-1]) as called at
   classification/har/adbox.py:20.  scipy IS installed, so this restatement is
-  pinned bit-for-bit by the third-party call itself (tests/golden/har_*.npy).
+  pinned bit-for-bit by the third-party call itself (tests/golden/har_stft.npz).
 * frame_signal -> classification/vggsound/utils/transforms.py:19-61 (identical
   copies under recognition/ and retrieval/).  Pinned by outputs of the
-  reference function itself (tests/golden/frame_signal_*.npy).
+  reference function itself (tests/golden/frame_signal.npz).
 * whisper_logmel -> not in the reference at all; the "n_fft=400 hop=160 80-mel
   30 s" configuration is defined by transformers' WhisperFeatureExtractor and
   is restated here only so the throughput configuration has a checker.
