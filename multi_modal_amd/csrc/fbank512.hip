@@ -511,6 +511,43 @@ static bool build_mel4(Plan& plan, bool align) {
     if (pick < 0) return false;
     const int NGA = kMel4Shapes[pick].nga, NGB = kMel4Shapes[pick].ngb;
     const int total_steps = 4 * (NGA + NGB);
+    // Free bank-conflict reduction: a block whose run is shorter than its set's step count may start its run a
+    // few bins early (the extra leading steps carry zero weights).  The A operands of the 8 blocks that share
+    // a 32-lane half land on distinct LDS banks when their run starts are distinct modulo 8, so slide each
+    // run, within its slack, to a residue its half has not used yet (least flexible blocks choose first).
+    if (!align && !(std::getenv("MMFE_MEL_SLIDE") != nullptr && std::string(std::getenv("MMFE_MEL_SLIDE")) == "0")) {
+        for (int h = 0; h < 2; ++h) {
+            const int budget = 4 * (h == 0 ? NGA : NGB);
+            for (int half = 0; half < 2; ++half) {
+                int run[8], order[8];
+                bool used[8] = {false, false, false, false, false, false, false, false};
+                for (int i = 0; i < 8; ++i) {
+                    const int blk = 8 * half + i;
+                    int kmax = -1;
+                    for (int j = 0; j < 4; ++j) {
+                        const int m = 64 * h + 4 * blk + j;
+                        if (h >= nsets || m >= s.n_mel || plan.band_len[m] == 0) continue;
+                        kmax = std::max(kmax, (int)(plan.band_start[m] + plan.band_len[m] - 1));
+                    }
+                    run[i] = kmax < 0 ? 0 : kmax - kstart[h][blk] + 1;
+                    order[i] = i;
+                }
+                std::sort(order, order + 8, [&](int x, int y) { return run[x] > run[y]; });   // longest run = least slack first
+                for (int oi = 0; oi < 8; ++oi) {
+                    const int i = order[oi], blk = 8 * half + i;
+                    const int slack = run[i] == 0 ? 7 : std::min(7, budget - run[i]);
+                    int chosen = 0;
+                    for (int sh = 0; sh <= slack; ++sh) {
+                        const int cand = kstart[h][blk] - sh;
+                        if (cand < -kPGuard) break;
+                        if (!used[((cand % 8) + 8) % 8]) { chosen = sh; break; }
+                    }
+                    kstart[h][blk] -= chosen;
+                    used[((kstart[h][blk] % 8) + 8) % 8] = true;
+                }
+            }
+        }
+    }
     // every run must stay inside the frame's LDS tile
     for (int h = 0; h < 2; ++h)
         for (int blk = 0; blk < 16; ++blk)

@@ -125,6 +125,63 @@ def test_fbank_generic_path_non_512(mm, O):
     assert p999 <= 1e-4 and mx <= 2e-3
 
 
+def test_fbank_unaligned_and_strided_inputs(mm, O):
+    """Rows that start at odd sample offsets (4-byte aligned only), odd row strides and row views of a wider
+    buffer take the scalar-load kernel variants; results must not depend on alignment."""
+    base = torch.from_numpy(np.stack([synth("noise0.1", 160001, 50 + i) for i in range(3)])).cuda()
+    ref = torch.stack([O.preprocessing_audio(base[i:i + 1, 1:].cpu()) for i in range(3)]).numpy()
+    got_view = mm.preprocessing_audio_batch(base[:, 1:]).cpu().numpy()            # odd offset, odd stride (160001)
+    got_copy = mm.preprocessing_audio_batch(base[:, 1:].contiguous()).cpu().numpy()
+    assert np.abs(got_view - ref).max() <= 5e-4 and np.abs(got_copy - ref).max() <= 5e-4
+    # two kernel variants (scalar vs 8-byte loads): same algorithm, separately compiled, so fp32 rounding of the
+    # FFT may differ in the last bit and near-empty mel cells amplify that like any other fp32 difference
+    assert np.abs(got_view - got_copy).max() <= 5e-4
+    wide = torch.zeros(3, 200000, device="cuda")
+    wide[:, :160000] = base[:, :160000]
+    assert torch.equal(mm.preprocessing_audio_batch(wide[:, :160000]), mm.preprocessing_audio_batch(base[:, :160000].contiguous()))
+    # non-unit inner stride falls back to a contiguous copy
+    inter = torch.zeros(2, 320000, device="cuda")
+    inter[:, ::2] = base[:2, :160000]
+    assert torch.equal(mm.preprocessing_audio_batch(inter[:, ::2]), mm.preprocessing_audio_batch(base[:2, :160000].contiguous()))
+
+
+def test_fbank_odd_window_and_hop(mm, O):
+    """22.05 kHz, 25 ms -> 551-tap window (odd), n_fft 1024, hop 220: served by the any-length DFT kernel;
+    11.025 kHz -> 275 taps, n_fft 512, hop 110: the 512 kernel with an odd window (scalar loads)."""
+    x = synth("noise0.1", 30000, 77)
+    for sf, nm in [(22050.0, 40), (11025.0, 64)]:
+        ref = O.kaldi_fbank(torch.from_numpy(x)[None], sample_frequency=sf, num_mel_bins=nm).numpy()
+        got = mm.fbank(torch.from_numpy(x)[None].cuda(), sample_frequency=sf, num_mel_bins=nm).cpu().numpy()
+        assert got.shape == ref.shape
+        mx, p999 = _stats(got - ref)
+        assert p999 <= 1e-4 and mx <= 2e-3
+
+
+def test_fbank_valu_mel_form_matches(mm, O):
+    """The general (VALU) form of the banded mel projection and the matrix-pipe form give the same features."""
+    import os
+    x = torch.from_numpy(np.stack([synth("noise0.1", 160000, 90), synth("uniform", 160000, 91)])).cuda()
+    a = mm.preprocessing_audio_batch(x).clone()
+    from multi_modal_amd import plans
+    os.environ["MMFE_MEL_FORM"] = "valu"
+    try:
+        plans.clear_plans()
+        b = mm.preprocessing_audio_batch(x).clone()
+    finally:
+        del os.environ["MMFE_MEL_FORM"]
+        plans.clear_plans()
+    assert (a - b).abs().max().item() <= 2e-6
+
+
+def test_har_unaligned_rows(mm, O):
+    rng = np.random.default_rng(3)
+    buf = rng.standard_normal((5, 6, 195)).astype(np.float32)
+    t = torch.from_numpy(buf).cuda()
+    got = mm.stft_mag(t[:, :, 1:194]).cpu().numpy()          # T = 193 (odd), rows start at odd offsets
+    ref = O.stft_mag(buf[:, :, 1:194])
+    assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-6
+
+
 def test_fbank_unsupported_raise(mm):
     x = torch.zeros(1, 16000)
     for kw in [dict(dither=1.0), dict(use_energy=True), dict(vtln_warp=1.1), dict(snip_edges=False), dict(subtract_mean=True)]:
