@@ -44,6 +44,19 @@ constexpr int kPGuard = 8;                   // floats in front of the power spe
 #ifndef MMFE_FBANK_MIN_WAVES_PER_SIMD
 #define MMFE_FBANK_MIN_WAVES_PER_SIMD 3
 #endif
+// output stores: the feature tensor is far larger than the caches, so it can bypass them (1) or not (0)
+#ifndef MMFE_FBANK_NTLOAD
+#define MMFE_FBANK_NTLOAD 0
+#endif
+#ifndef MMFE_FBANK_NT
+#define MMFE_FBANK_NT 1
+#endif
+#if MMFE_FBANK_NT
+#define MMFE_OUT_STORE(v, ptr) __builtin_nontemporal_store((v), (ptr))
+#else
+#define MMFE_OUT_STORE(v, ptr) (*(ptr) = (v))
+#endif
+
 #ifndef MMFE_PREFETCH_AT
 #define MMFE_PREFETCH_AT 1   // 0: after the first-half transpose write, 1: after the second-half spectrum write
 #endif
@@ -116,7 +129,13 @@ __device__ __forceinline__ void load_frame(float2 (&v)[NA], const float* fp, con
         const bool whole = EXACT && a < NA - 1;        // compile-time: slice entirely inside the window
         if (VEC2) {
             const bool ok = whole || idx + 1 < win_len;
+#if MMFE_FBANK_NTLOAD
+            typedef float vf2 __attribute__((ext_vector_type(2)));
+            const vf2 rr = __builtin_nontemporal_load(reinterpret_cast<const vf2*>(ok ? base + 32 * a : safe));
+            const float2 r = make_float2(rr.x, rr.y);
+#else
             const float2 r = *reinterpret_cast<const float2*>(ok ? base + 32 * a : safe);
+#endif
             v[a] = whole ? r : make_float2(ok ? r.x : 0.f, ok ? r.y : 0.f);
         } else {
             const bool ok0 = whole || idx < win_len, ok1 = whole || idx + 1 < win_len;
@@ -399,11 +418,11 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
             if (lane < p.n_mel) {
 #endif
 #pragma unroll
-                for (int r = 0; r < 4; ++r) obase[r < n_ok ? r * p.n_mel : 0] = r < n_ok ? va[r] : va[0];
+                for (int r = 0; r < 4; ++r) MMFE_OUT_STORE(r < n_ok ? va[r] : va[0], obase + (r < n_ok ? r * p.n_mel : 0));
             }
             if (NGB > 0 && 64 + lane < p.n_mel) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) obase[64 + (r < n_ok ? r * p.n_mel : 0)] = r < n_ok ? vb[r] : vb[0];
+                for (int r = 0; r < 4; ++r) MMFE_OUT_STORE(r < n_ok ? vb[r] : vb[0], obase + 64 + (r < n_ok ? r * p.n_mel : 0));
             }
         } else {
             const int t = t0 + fl;

@@ -47,11 +47,25 @@ __device__ __forceinline__ float2 tw32(int k) {
     return make_float2(-S[k], -S[8 - k]);
 }
 
-// One group = R consecutive rows.  Three phases separated by block barriers:
-//   stage  coalesced global reads -> LDS rows with zero margins (scipy's zero boundary extension + padding)
+// Block barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter,
+// i.e. it would wait for the drain phase's global stores to reach memory at every phase change.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+constexpr int kPrefetch = 4;     // float4 registers per thread for the next group's samples
+
+// One group = R consecutive rows, three phases:
+//   stage  the group's samples (prefetched into registers two groups ahead, coalesced 16-byte reads) are
+//          dropped into LDS rows whose zero margins (scipy's boundary extension + padding) are written once;
+//          this happens between the previous group's work and drain, so neither the loads nor the
+//          drain's stores are waited for right after they are issued
 //   work   one lane per frame: eight 16-byte LDS reads, 32-point real FFT in registers, 17 magnitudes
 //          written to an LDS image of the group's output block, laid out exactly like global memory
-//   drain  the output block is contiguous in global memory: 16-byte coalesced stores
+//   drain  the output block is contiguous in global memory: 16-byte coalesced stores, left in flight while
+//          the next group is staged and worked on (barriers order LDS only)
 template <bool ALIGNED_HOP>
 __global__ void __launch_bounds__(kMaxThreads) stft32_kernel(const StftArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -62,26 +76,48 @@ __global__ void __launch_bounds__(kMaxThreads) stft32_kernel(const StftArgs p) {
     float* s_out = s_in + R * p.row_lds;                             // R * 17 * S
     const int n_groups = (p.n_rows + R - 1) / R;
     const int nthr = blockDim.x;
+    const int T4 = T >> 2;
+    const bool prefetch = p.vec_in && R * T4 <= kPrefetch * nthr;
 
-    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    for (int i = threadIdx.x; i < R * (p.row_lds - T); i += nthr) {   // zero margins: never overwritten
+        const int r = i / (p.row_lds - T);
+        int j = i - r * (p.row_lds - T);
+        j = j < 16 ? j : j + T;
+        s_in[r * p.row_lds + j] = 0.f;
+    }
+
+    float4 pf[kPrefetch];
+    auto fetch = [&](int grp) {
         const int row0 = grp * R;
         const int rows = min(R, p.n_rows - row0);
-        __syncthreads();   // the previous group's drain is done with s_out, its workers with s_in
-        // ---- stage ----------------------------------------------------------------------------------
-        for (int i = threadIdx.x; i < rows * (p.row_lds - T); i += nthr) {          // zero margins
-            const int r = i / (p.row_lds - T);
-            int j = i - r * (p.row_lds - T);
-            j = j < 16 ? j : j + T;
-            s_in[r * p.row_lds + j] = 0.f;
+        const float4* g4 = reinterpret_cast<const float4*>(p.src.base + (int64_t)row0 * T);
+#pragma unroll
+        for (int q = 0; q < kPrefetch; ++q) {
+            const int i = threadIdx.x + q * nthr;
+            pf[q] = (grp < n_groups && i < rows * T4) ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (p.vec_in) {
+    };
+    // put group `grp`'s samples into the LDS rows (from the prefetch registers when they hold them)
+    auto stage = [&](int grp) {
+        if (grp >= n_groups) return;
+        const int row0 = grp * R;
+        const int rows = min(R, p.n_rows - row0);
+        if (prefetch) {
+#pragma unroll
+            for (int q = 0; q < kPrefetch; ++q) {
+                const int i = threadIdx.x + q * nthr;
+                if (i < rows * T4) {
+                    const int r = i / T4;
+                    const int j4 = i - r * T4;
+                    *reinterpret_cast<float4*>(s_in + r * p.row_lds + 16 + 4 * j4) = pf[q];
+                }
+            }
+        } else if (p.vec_in) {
             const float4* g4 = reinterpret_cast<const float4*>(p.src.base + (int64_t)row0 * T);
-            const int T4 = T >> 2;
             for (int i = threadIdx.x; i < rows * T4; i += nthr) {
                 const int r = i / T4;
                 const int j4 = i - r * T4;
-                const float4 v = g4[i];
-                *reinterpret_cast<float4*>(s_in + r * p.row_lds + 16 + 4 * j4) = v;
+                *reinterpret_cast<float4*>(s_in + r * p.row_lds + 16 + 4 * j4) = g4[i];
             }
         } else {
             for (int i = threadIdx.x; i < rows * T; i += nthr) {
@@ -90,7 +126,15 @@ __global__ void __launch_bounds__(kMaxThreads) stft32_kernel(const StftArgs p) {
                 s_in[r * p.row_lds + 16 + j] = row_ptr(p.src, row0 + r)[j];
             }
         }
-        __syncthreads();
+    };
+    if (prefetch) fetch(blockIdx.x);
+    stage(blockIdx.x);
+    if (prefetch) fetch(blockIdx.x + gridDim.x);
+    lds_barrier();
+
+    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int row0 = grp * R;
+        const int rows = min(R, p.n_rows - row0);
         // ---- work: one frame per lane ---------------------------------------------------------------
         const int n_fr = rows * S;
         for (int f = threadIdx.x; f < n_fr; f += nthr) {
@@ -129,19 +173,25 @@ __global__ void __launch_bounds__(kMaxThreads) stft32_kernel(const StftArgs p) {
                 if (k != 8) o[(16 - k) * S] = pb;
             }
         }
-        __syncthreads();
+        lds_barrier();      // output image complete; every wave is done reading s_in
+        // ---- stage the next group (its loads were issued a whole work phase ago), refill the prefetch --------
+        stage(grp + gridDim.x);
+        if (prefetch) fetch(grp + 2 * gridDim.x);
         // ---- drain ----------------------------------------------------------------------------------
         const int n_out = rows * 17 * S;
         float* gout = p.out + (int64_t)row0 * 17 * S;
         if (p.vec_out) {
+            // the output tensor is far larger than the caches and is not read back here: stream it past them
+            typedef float vf4 __attribute__((ext_vector_type(4)));
             const int n4 = n_out >> 2;
-            float4* g4 = reinterpret_cast<float4*>(gout);
-            const float4* l4 = reinterpret_cast<const float4*>(s_out);
-            for (int i = threadIdx.x; i < n4; i += nthr) g4[i] = l4[i];
+            vf4* g4 = reinterpret_cast<vf4*>(gout);
+            const vf4* l4 = reinterpret_cast<const vf4*>(s_out);
+            for (int i = threadIdx.x; i < n4; i += nthr) __builtin_nontemporal_store(l4[i], g4 + i);
             for (int i = 4 * n4 + threadIdx.x; i < n_out; i += nthr) gout[i] = s_out[i];
         } else {
             for (int i = threadIdx.x; i < n_out; i += nthr) gout[i] = s_out[i];
         }
+        lds_barrier();      // next group's samples visible; every wave is done reading s_out
     }
 }
 
@@ -178,17 +228,15 @@ int stft32_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
     // LDS row: 16 leading zeros + samples + zeros up to the end of the last frame
     const int need = (int)((n_frames - 1) * s.hop + kN);
     a.row_lds = (std::max(need, (int)n_samples + 16) + 3) & ~3;
-    // rows per group R (a multiple of 4 keeps every group's output block 16-byte aligned) and block size:
-    // one lane per frame, pick the R that wastes the fewest lanes while 2+ blocks still fit in a CU's LDS
+    // rows per group R: a multiple of 4 keeps every group's output block 16-byte aligned.  The kernel is bound
+    // by its output stores, and the largest group that fits LDS measured fastest (fewest barriers per byte;
+    // lane efficiency of the last pass over the frames matters less), one block per CU.
     const int64_t per_row_bytes = ((int64_t)a.row_lds + 17 * n_frames) * 4;
     int best_r = 0, best_threads = 0;
-    double best_eff = -1.0;
     for (int r = 4; r <= 64; r += 4) {
-        if (r * per_row_bytes > 100 * 1024) break;
-        const int64_t fr = (int64_t)r * n_frames;
-        const int64_t thr = std::min<int64_t>(kMaxThreads, (fr + 63) / 64 * 64);
-        const double eff = (double)fr / (double)((fr + thr - 1) / thr * thr);
-        if (eff > best_eff + 0.005) { best_eff = eff; best_r = r; best_threads = (int)thr; }
+        if (r * per_row_bytes > 144 * 1024) break;
+        best_r = r;
+        best_threads = (int)std::min<int64_t>(kMaxThreads, ((int64_t)r * n_frames + 63) / 64 * 64);
     }
     if (const char* force = std::getenv("MMFE_STFT_ROWS")) {   // tuning override: rows per group
         const int r = std::atoi(force);
@@ -196,6 +244,10 @@ int stft32_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
             best_r = r;
             best_threads = (int)std::min<int64_t>(kMaxThreads, ((int64_t)r * n_frames + 63) / 64 * 64);
         }
+    }
+    if (const char* force = std::getenv("MMFE_STFT_THREADS")) {   // tuning override: block size
+        const int t = std::atoi(force);
+        if (t >= 64 && t <= kMaxThreads && t % 64 == 0) best_threads = t;
     }
     if (best_r == 0) {   // very long rows: one row per group, frames looped over the block
         best_r = 1;
@@ -214,8 +266,6 @@ int stft32_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
     MMFE_HIP_CHECK(hipGetDevice(&dev));
     MMFE_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int64_t groups = (n_rows + best_r - 1) / best_r;
-    const int blocks_per_cu = std::max(1, std::min<int>((int)((160 * 1024) / lds), 2048 / best_threads));
-    const int grid = (int)std::min<int64_t>(groups, (int64_t)cus * blocks_per_cu);
     const bool aligned_hop = s.hop % 4 == 0;
     static unsigned long long done_mask[2] = {0, 0};
     const void* fn = aligned_hop ? reinterpret_cast<const void*>(&stft32_kernel<true>) : reinterpret_cast<const void*>(&stft32_kernel<false>);
@@ -223,6 +273,10 @@ int stft32_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
         MMFE_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         done_mask[aligned_hop] |= 1ull << (dev & 63);
     }
+    // persistent blocks: exactly as many as are resident at once (registers, LDS and wave slots all count)
+    int blocks_per_cu = 1;
+    MMFE_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, best_threads, lds));
+    const int grid = (int)std::min<int64_t>(groups, (int64_t)cus * std::max(1, blocks_per_cu));
     if (aligned_hop) hipLaunchKernelGGL(stft32_kernel<true>, dim3(grid), dim3(best_threads), lds, stream, a);
     else hipLaunchKernelGGL(stft32_kernel<false>, dim3(grid), dim3(best_threads), lds, stream, a);
     MMFE_HIP_CHECK(hipGetLastError());
