@@ -156,6 +156,11 @@ int mmfe_run_slices(const mmfe_plan* plan, const float* recs, const int64_t* rec
  * caller zeroes them).  Stands for the two DataLoader passes of cal_norm (vggsound.py:85-107). */
 int mmfe_feature_sums(const float* x, int64_t n, double* sums, int device, void* hip_stream);
 
+/* Name of the kernel family that serves the plan ("fbank512", "rfft400", "dftgen", "stft32", "frame"); a static
+ * string, never NULL.  Diagnostic: the reference has one code path per transform, so nothing there corresponds;
+ * tests use it to make sure a parameter set reaches the kernel they mean to exercise. */
+const char* mmfe_plan_kernel(const mmfe_plan* plan);
+
 #ifdef __cplusplus
 }
 #endif

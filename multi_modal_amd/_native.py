@@ -27,6 +27,7 @@ LAYOUT_TIME_MAJOR, LAYOUT_FEAT_MAJOR = 0, 1
 EXPORTED_SYMBOLS = (
     "mmfe_abi_version", "mmfe_last_error", "mmfe_device_count", "mmfe_spec_out_shape",
     "mmfe_plan_create", "mmfe_plan_destroy", "mmfe_run", "mmfe_run_slices", "mmfe_feature_sums",
+    "mmfe_plan_kernel",
 )
 
 
@@ -106,6 +107,8 @@ def load_library():
                                         c_i64, c_i64, c_f_p, ctypes.c_void_p]
         lib.mmfe_feature_sums.restype = ctypes.c_int
         lib.mmfe_feature_sums.argtypes = [c_f_p, c_i64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        lib.mmfe_plan_kernel.restype = ctypes.c_char_p
+        lib.mmfe_plan_kernel.argtypes = [ctypes.c_void_p]
         if lib.mmfe_abi_version() != ABI_VERSION:
             raise MmfeError(f"{path} has ABI version {lib.mmfe_abi_version()}, the Python side expects {ABI_VERSION}")
         _lib = lib
@@ -181,6 +184,11 @@ class Plan:
         check(self._lib.mmfe_run_slices(self._handle, recs_ptr, rec_start_ptr, rec_index_ptr, offsets_ptr, int(n_rows),
                                         int(n_samples), out_ptr, ctypes.c_void_p(stream) if stream else None),
               "mmfe_run_slices")
+
+    @property
+    def kernel(self) -> str:
+        """Name of the kernel family serving this plan (diagnostic)."""
+        return self._lib.mmfe_plan_kernel(self._handle).decode()
 
     def close(self) -> None:
         if getattr(self, "_handle", None):

@@ -56,18 +56,6 @@ struct DftArgs {
     const float* band_w;
 };
 
-__device__ __forceinline__ float fetch_sample(const float* row, int i, int n, int pad_mode) {
-    if (i >= 0 && i < n) return row[i];
-    if (pad_mode == MMFE_PAD_REFLECT) {
-        if (n == 1) return row[0];
-        const int period = 2 * (n - 1);
-        int m = i % period;
-        if (m < 0) m += period;
-        return row[m < n ? m : period - m];
-    }
-    return 0.f;
-}
-
 // `log_of_floor` is log(floor) rounded on the host, so floored cells carry the same value the
 // reference's CPU libm produces (device logf is within 1 ulp, not correctly rounded).
 __device__ __forceinline__ float dft_log(float x, int kind, float floor_, float log_of_floor) {
@@ -77,12 +65,6 @@ __device__ __forceinline__ float dft_log(float x, int kind, float floor_, float 
         case MMFE_LOG_LOG10_MAX: return x <= floor_ ? log_of_floor : log10f(x);
         default: return x;
     }
-}
-
-// monotone map float -> int so that atomicMax on ints orders floats
-__device__ __forceinline__ int float_to_ordered(float f) {
-    const int i = __float_as_int(f);
-    return i >= 0 ? i : i ^ 0x7fffffff;
 }
 
 __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
@@ -230,6 +212,30 @@ __global__ void clamp_affine_kernel(float* out, const int* rowmax, int64_t per_r
 
 }  // namespace
 
+int rowmax_init_launch(const Plan& plan, int64_t n_rows, hipStream_t stream) {
+    if (plan.d_rowmax == nullptr || n_rows > plan.rowmax_capacity) {
+        set_error("clamp_below_max supports at most %lld rows per call", (long long)plan.rowmax_capacity);
+        return MMFE_EINVAL;
+    }
+    hipLaunchKernelGGL(rowmax_init_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<int*>(plan.d_rowmax), (int)n_rows);
+    MMFE_HIP_CHECK(hipGetLastError());
+    return MMFE_OK;
+}
+
+int clamp_affine_launch(const Plan& plan, float* out, int64_t n_rows, int64_t per_row, hipStream_t stream) {
+    const mmfe_spec& s = plan.spec;
+    int dev = 0, cus = 256;
+    MMFE_HIP_CHECK(hipGetDevice(&dev));
+    MMFE_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int64_t total = per_row * n_rows;
+    const int grid = (int)std::min<int64_t>((total + 255) / 256, (int64_t)cus * 16);
+    hipLaunchKernelGGL(clamp_affine_kernel, dim3(grid), dim3(256), 0, stream, out, reinterpret_cast<const int*>(plan.d_rowmax),
+                       per_row, total, s.clamp_below_max, s.out_shift, s.out_scale);
+    MMFE_HIP_CHECK(hipGetLastError());
+    return MMFE_OK;
+}
+
 int dftgen_prepare(Plan& plan) {
     const mmfe_spec& s = plan.spec;
     if (s.n_fft < 2 || s.n_fft > 4096 || s.win_len < 1 || s.win_off < 0 || s.win_off + s.win_len > s.n_fft) {
@@ -300,14 +306,9 @@ int dftgen_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
 
     const bool clamp = s.clamp_below_max > 0.f;
     if (clamp) {
-        if (n_rows > plan.rowmax_capacity) {
-            set_error("dftgen: clamp_below_max supports at most %lld rows per call", (long long)plan.rowmax_capacity);
-            return MMFE_EINVAL;
-        }
+        int rc = rowmax_init_launch(plan, n_rows, stream);
+        if (rc) return rc;
         a.rowmax = plan.d_rowmax;
-        hipLaunchKernelGGL(rowmax_init_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream,
-                           reinterpret_cast<int*>(plan.d_rowmax), (int)n_rows);
-        MMFE_HIP_CHECK(hipGetLastError());
     }
     const size_t lds = (size_t)s.n_fft * 16 + (size_t)s.win_len * FR * 8 + (size_t)FR * (plan.n_bins + 1) * 4;
     if (lds > 160 * 1024) {
@@ -327,15 +328,7 @@ int dftgen_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
     const int grid = (int)std::min<int64_t>(work, (int64_t)cus * 8);
     hipLaunchKernelGGL(dftgen_kernel, dim3(grid), dim3(kThreads), lds, stream, a);
     MMFE_HIP_CHECK(hipGetLastError());
-    if (clamp) {
-        const int64_t per_row = out_frames * a.n_feat;
-        const int64_t total = per_row * n_rows;
-        const int g2 = (int)std::min<int64_t>((total + 255) / 256, (int64_t)cus * 16);
-        hipLaunchKernelGGL(clamp_affine_kernel, dim3(g2), dim3(256), 0, stream, out,
-                           reinterpret_cast<const int*>(plan.d_rowmax), per_row, total, s.clamp_below_max, s.out_shift,
-                           s.out_scale);
-        MMFE_HIP_CHECK(hipGetLastError());
-    }
+    if (clamp) return clamp_affine_launch(plan, out, n_rows, out_frames * a.n_feat, stream);
     return MMFE_OK;
 }
 

@@ -25,6 +25,7 @@
 // cover each frame's 128-byte lines exactly once) and every output float is written once.
 #include "mmfe_internal.h"
 #include "fft_regs.h"
+#include "log_affine.h"
 
 #include <algorithm>
 #include <cmath>
@@ -74,17 +75,6 @@ constexpr int kTwPostEntries = 144;          // -i*W512^k for k = 0..143
 constexpr int kMaxPass = MelPassTable::kMaxPass;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct LogAffine {
-    float max_with;     // floor for the max kinds, -inf otherwise
-    float add_to;       // epsilon for the add kind, 0 otherwise
-    float mul;          // log-base change * out_scale
-    float add;          // out_shift * out_scale
-    float floor_cmp;    // floor for the max kinds, -inf otherwise
-    float floor_val;    // value of floored cells
-    float out_shift, out_scale;
-    float none_flag;    // 1 when there is no log at all
-};
 
 struct FbankArgs {
     RowSource src;
@@ -144,22 +134,6 @@ __device__ __forceinline__ void load_frame(float2 (&v)[NA], const float* fp, con
             v[a] = make_float2(ok0 ? r0 : 0.f, ok1 ? r1 : 0.f);
         }
     }
-}
-
-// Branch-free log + affine stage: result = (log(x) + out_shift) * out_scale, with the log taken by the
-// hardware base-2 logarithm (v_log_f32, about 1 ulp of log2) and the base change folded into one fma:
-//   result = log2(arg) * (ln2 * out_scale) + out_shift * out_scale.
-// Absolute error of the log is below 4e-6 over the range of spectra (|log| <= 30), far inside the
-// tolerance.  Floored cells (x <= floor) take `floor_val` = (log(floor) + out_shift) * out_scale computed
-// on the host from the host libm's log, the value the reference's CPU path produces.
-// The log kind is encoded as DATA (see make_log_affine), never as control flow: hipcc turns selects on
-// wave-uniform conditions into scalar branches, and a taken branch per value costs more than the log.
-__device__ __forceinline__ float apply_log_affine(float x, const LogAffine& L, float none_flag) {
-    const float arg = fmaxf(x, L.max_with) + L.add_to;            // max kinds: max(x, floor) + 0;  add kind: x + eps
-    float v = fmaf(__builtin_amdgcn_logf(arg), L.mul, L.add);
-    v = x <= L.floor_cmp ? L.floor_val : v;                       // floor_cmp = -inf unless a max kind
-    const float lin = (x + L.out_shift) * L.out_scale;
-    return none_flag != 0.f ? lin : v;                            // per-lane flag (kept opaque to the optimiser)
 }
 
 // Diagnostic build only (-DMMFE_STAMPS): per-phase s_memtime shares of the main loop, printed by the launcher.
@@ -703,20 +677,7 @@ int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
     a.n_mel = s.n_mel;
     a.preemph = s.preemph;
     a.mean_scale = s.remove_dc ? 1.0f / (float)s.win_len : 0.0f;
-    {
-        const bool is_max = s.log_kind == MMFE_LOG_LN_MAX || s.log_kind == MMFE_LOG_LOG10_MAX;
-        const double base = s.log_kind == MMFE_LOG_LOG10_MAX ? 0.30102999566398119521 : 0.69314718055994530942;   // log10(2), ln(2)
-        const float lof = s.log_kind == MMFE_LOG_LOG10_MAX ? (float)std::log10((double)s.log_floor) : (float)std::log((double)s.log_floor);
-        a.la.max_with = is_max ? s.log_floor : -INFINITY;
-        a.la.add_to = s.log_kind == MMFE_LOG_LN_ADD ? s.log_floor : 0.0f;
-        a.la.mul = (float)(base * (double)s.out_scale);
-        a.la.add = (float)((double)s.out_shift * (double)s.out_scale);
-        a.la.floor_cmp = is_max ? s.log_floor : -INFINITY;
-        a.la.floor_val = (lof + s.out_shift) * s.out_scale;
-        a.la.out_shift = s.out_shift;
-        a.la.out_scale = s.out_scale;
-        a.la.none_flag = s.log_kind == MMFE_LOG_NONE ? 1.0f : 0.0f;
-    }
+    a.la = make_log_affine(s);
     a.window = plan.d_window;
     a.tw_stage = reinterpret_cast<const float2*>(plan.d_tw_a);
     a.tw_post = reinterpret_cast<const float2*>(plan.d_tw_b);

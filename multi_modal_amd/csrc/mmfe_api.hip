@@ -102,7 +102,7 @@ void free_plan(Plan* p) {
     if (p == nullptr) return;
     (void)hipFree(p->d_window); (void)hipFree(p->d_tw_a); (void)hipFree(p->d_tw_b); (void)hipFree(p->d_tw64); (void)hipFree(p->d_window64);
     (void)hipFree(p->d_mel_start); (void)hipFree(p->d_mel_w); (void)hipFree(p->d_mel_niter); (void)hipFree(p->d_mel_woff);
-    (void)hipFree(p->d_mel4_kstart); (void)hipFree(p->d_mel4_w);
+    (void)hipFree(p->d_mel4_kstart); (void)hipFree(p->d_mel4_w); (void)hipFree(p->d_r400_dst);
     (void)hipFree(p->d_band_start); (void)hipFree(p->d_band_len); (void)hipFree(p->d_band_off); (void)hipFree(p->d_band_w);
     (void)hipFree(p->d_rowmax);
     delete p;
@@ -124,6 +124,7 @@ int run_common(const Plan* plan, const RowSource& src, int64_t n_rows, int64_t n
     switch (plan->impl) {
         case IMPL_FBANK512: rc = fbank512_launch(*plan, src, n_rows, n_samples, natural, frames, out, stream); break;
         case IMPL_DFT_GENERIC: rc = dftgen_launch(*plan, src, n_rows, n_samples, natural, frames, out, stream); break;
+        case IMPL_RFFT400: rc = rfft400_launch(*plan, src, n_rows, n_samples, natural, frames, out, stream); break;
         case IMPL_STFT32: rc = stft32_launch(*plan, src, n_rows, n_samples, frames, out, stream); break;
         case IMPL_FRAME: rc = frame_launch(*plan, src, n_rows, n_samples, frames, out, stream); break;
         default: set_error("plan has no implementation"); rc = MMFE_EINVAL;
@@ -213,6 +214,7 @@ int mmfe_plan_create(const mmfe_spec* spec, const void* window, const int32_t* b
                 break;
             }
             if (spec->n_fft == 512 && spec->win_off == 0) { p->impl = IMPL_FBANK512; rc = fbank512_prepare(*p); }
+            else if (rfft400_supports(*spec) && rfft400_prepare(*p) == MMFE_OK) p->impl = IMPL_RFFT400;
             else { p->impl = IMPL_DFT_GENERIC; rc = dftgen_prepare(*p); }
             break;
         case MMFE_KIND_LOGSPEC:
@@ -221,8 +223,14 @@ int mmfe_plan_create(const mmfe_spec* spec, const void* window, const int32_t* b
                 rc = MMFE_EINVAL;
                 break;
             }
-            p->impl = IMPL_DFT_GENERIC;
-            rc = dftgen_prepare(*p);
+            // n_fft = 400 with a mel bank has a radix kernel; everything else (and mel banks whose shape that
+            // kernel has no variant for) goes to the any-length kernel
+            p->impl = 0;
+            if (rfft400_supports(*spec) && rfft400_prepare(*p) == MMFE_OK) p->impl = IMPL_RFFT400;
+            if (p->impl == 0) {
+                p->impl = IMPL_DFT_GENERIC;
+                rc = dftgen_prepare(*p);
+            }
             if (rc == MMFE_OK && spec->clamp_below_max > 0.f) {
                 p->rowmax_capacity = 1 << 20;
                 if (hipMalloc((void**)&p->d_rowmax, (size_t)p->rowmax_capacity * sizeof(float)) != hipSuccess) {
@@ -280,6 +288,19 @@ int mmfe_feature_sums(const float* x, int64_t n, double* sums, int device, void*
     DeviceGuard guard(device);
     if (!guard.ok) { set_error("cannot make device %d current", device); return MMFE_EHIP; }
     return feature_sums_launch(x, n, sums, reinterpret_cast<hipStream_t>(hip_stream));
+}
+
+const char* mmfe_plan_kernel(const mmfe_plan* plan) {
+    const Plan* p = reinterpret_cast<const Plan*>(plan);
+    if (p == nullptr) return "none";
+    switch (p->impl) {
+        case IMPL_FBANK512: return "fbank512";
+        case IMPL_RFFT400: return "rfft400";
+        case IMPL_DFT_GENERIC: return "dftgen";
+        case IMPL_STFT32: return "stft32";
+        case IMPL_FRAME: return "frame";
+        default: return "none";
+    }
 }
 
 }  // extern "C"

@@ -35,6 +35,25 @@ __device__ __forceinline__ const float* row_ptr(const RowSource& s, int64_t r) {
     return s.base + s.rec_start[s.rec_index[r]] + s.offsets[r];
 }
 
+// Sample i of a row of n samples under the plan's padding rule (i may lie outside the row).
+__device__ __forceinline__ float fetch_sample(const float* row, int i, int n, int pad_mode) {
+    if (i >= 0 && i < n) return row[i];
+    if (pad_mode == MMFE_PAD_REFLECT) {
+        if (n == 1) return row[0];
+        const int period = 2 * (n - 1);
+        int m = i % period;
+        if (m < 0) m += period;
+        return row[m < n ? m : period - m];
+    }
+    return 0.f;
+}
+
+// monotone map float -> int so that atomicMax on ints orders floats
+__device__ __forceinline__ int float_to_ordered(float f) {
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+
 // ---------------------------------------------------------------------------------------------
 // mel filter bank in the layout the radix kernels consume: filters are taken 16 at a time
 // ("pass" j holds filters 16j .. 16j+15, one per lane of a 16-lane frame group); inside a pass
@@ -73,6 +92,8 @@ struct Plan {
     int mel4_nga = 0, mel4_ngb = 0;   // matrix-pipe mel form: groups of 4 bins per filter set (0 = not used)
     int32_t* d_mel4_kstart = nullptr;
     float* d_mel4_w = nullptr;
+    int r400_shape = -1;              // n_fft = 400 kernel: index of the instantiated mel stream shape
+    int32_t* d_r400_dst = nullptr;    // n_fft = 400 kernel: (filter, frame group) served by each lane of each stream
     int32_t* d_band_start = nullptr;  // plain CSR copy (generic DFT kernel)
     int32_t* d_band_len = nullptr;
     int32_t* d_band_off = nullptr;
@@ -82,7 +103,7 @@ struct Plan {
     int impl = 0;                     // which kernel family serves this plan
 };
 
-enum Impl { IMPL_FBANK512 = 1, IMPL_STFT32 = 2, IMPL_DFT_GENERIC = 3, IMPL_FRAME = 4 };
+enum Impl { IMPL_FBANK512 = 1, IMPL_STFT32 = 2, IMPL_DFT_GENERIC = 3, IMPL_FRAME = 4, IMPL_RFFT400 = 5 };
 
 // launchers (one per translation unit)
 int fbank512_prepare(Plan& plan);
@@ -96,6 +117,15 @@ int stft32_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
 int dftgen_prepare(Plan& plan);
 int dftgen_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames_natural,
                   int64_t out_frames, float* out, hipStream_t stream);
+
+// per-row maximum + clamp pass of clamp_below_max: out = (max(out, rowmax - c) + out_shift) * out_scale
+int rowmax_init_launch(const Plan& plan, int64_t n_rows, hipStream_t stream);
+int clamp_affine_launch(const Plan& plan, float* out, int64_t n_rows, int64_t per_row, hipStream_t stream);
+
+bool rfft400_supports(const mmfe_spec& spec);
+int rfft400_prepare(Plan& plan);
+int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames_natural,
+                   int64_t out_frames, float* out, hipStream_t stream);
 
 int frame_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames,
                  float* out, hipStream_t stream);

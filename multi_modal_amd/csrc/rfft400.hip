@@ -1,0 +1,549 @@
+// Fused log-mel front-end for n_fft = 400 (25 ms frames at 16 kHz) on gfx950: framing with centre
+// reflect/zero padding or edge snipping -> window -> 400-point real FFT -> |X|^2 -> banded mel ->
+// log -> affine, spectra never leave the CU.  This is the long-utterance configuration
+// (n_fft 400, hop 160, 80 mel bands, 30 s utterances); its parameters are those of
+// transformers' WhisperFeatureExtractor, the reference itself has no n_fft = 400 caller.
+//
+// Mapping: 16 lanes own a PAIR of consecutive frames (A, B); a wave64 carries 8 consecutive frames
+// of one row per pass.
+//   * the wave's samples (7*hop + 400 of them) arrive by coalesced 16-byte loads, one pass ahead,
+//     and are laid out in LDS once, so the 2.5x overlap of neighbouring frames never re-reads HBM;
+//   * z[n] = w[n]*(A[n] + i*B[n]) is transformed by ONE 400-point complex FFT, split 25 x 16:
+//     lane b runs a register-resident 25-point FFT (radix 5 x 5) over z[16a+b], twiddles by
+//     W400^(b*c), the 16 lanes transpose through a padded LDS tile, and each lane runs the 16-point
+//     FFTs of columns c = b and c = b+16 (the second only for b <= 8), leaving Z[c + 25d];
+//   * the two real spectra separate as X_A[k] = (Z[k] + conj Z[400-k])/2 and
+//     X_B[k] = (Z[k] - conj Z[400-k])/(2i); the window is pre-halved, so |X_A|^2 and |X_B|^2 are two
+//     sums of squares per bin, written to LDS;
+//   * banded mel on the matrix pipe: v_mfma_f32_4x4x1 runs 16 independent blocks of (4 frames) x
+//     (4 filters); a block walks ITS OWN run of bins, one bin per instruction, weights resident in
+//     VGPRs.  The (filter block, frame group) units are spread over up to four instruction streams
+//     in order of frequency, so the short low-frequency runs do not wait for the long high ones; a
+//     last stream that is at most half full splits its runs in two and adds the halves.
+// Two waves per SIMD (LDS-bound occupancy) leave 256 VGPRs per lane: the window, the mel weights
+// and the prefetched samples all stay in registers.
+#include "mmfe_internal.h"
+#include "fft_regs.h"
+#include "log_affine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <string>
+
+namespace mmfe {
+
+namespace {
+
+constexpr int kN = 400;
+constexpr int kBins = 201;
+constexpr int kWaves = 4;                           // waves per block
+constexpr int kMaxHop = 160;
+constexpr int kMaxSpan = 7 * kMaxHop + kN;          // samples under one wave pass: 1520
+constexpr int kPF = (kMaxSpan / 4 + 63) / 64;       // prefetch registers (16-byte) per lane: 6
+constexpr int kTileStride = 18;                     // complex numbers per transpose-tile row (16 + padding, keeps rows 16-byte aligned)
+constexpr int kPairBytes = 25 * kTileStride * 8;    // 3600: transpose tile / natural-order spectrum of one frame pair
+constexpr int kWaveBytes = 4 * kPairBytes;          // 14400: one LDS work area per wave, reused by every phase
+constexpr int kPS = 216;                            // floats between the power spectra of consecutive frames (= 24 mod 64: 8 frames on 8 bank groups)
+constexpr int kPGuard = 8;                          // floats in front of bin 0 (a bin run may start below 0)
+constexpr int kTwBytes = 25 * 16 * 8;               // W400^(b*c) table, [c][b]
+constexpr int kStreams = 4;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Rfft400Args {
+    RowSource src;
+    float* out;
+    int* rowmax;               // per-row running maximum of the log values (ordered-int form), or nullptr
+    int n_rows;
+    int n_samples;
+    int frames_valid;          // frames computed per row
+    int out_frames;            // frames per row in the output tensor
+    int hop;
+    int shift;                 // DFT input position n of frame t holds sample t*hop + n + shift
+    int pad_mode;
+    int n_mel;
+    int layout;
+    int vec_store;             // feature-major rows may be stored 16 bytes at a time
+    LogAffine la;
+    const float* window;       // 400 floats: window pre-halved at win_off, zeros elsewhere
+    const float2* tw;          // [25][16]: W400^(b*c)
+    const int32_t* mel_poff;   // [kStreams][64]: float offset of the lane's bin run in the wave's spectrum area
+    const int32_t* mel_dst;    // [kStreams][64]: filter | frame group << 16, or -1 for an idle lane
+    const float* mel_w;        // [total steps][64], step-major
+};
+
+// 5-point forward DFT in place.
+__device__ __forceinline__ void dft5(float2& x0, float2& x1, float2& x2, float2& x3, float2& x4) {
+    constexpr float C1 = 0.30901699437494745f, C2 = -0.80901699437494734f;   // cos(2pi/5), cos(4pi/5)
+    constexpr float S1 = 0.95105651629515353f, S2 = 0.58778525229247325f;    // sin(2pi/5), sin(4pi/5)
+    const float2 t1 = cadd(x1, x4), t2 = cadd(x2, x3), t3 = csub(x1, x4), t4 = csub(x2, x3);
+    const float2 a1 = make_float2(fmaf(C2, t2.x, fmaf(C1, t1.x, x0.x)), fmaf(C2, t2.y, fmaf(C1, t1.y, x0.y)));
+    const float2 a2 = make_float2(fmaf(C1, t2.x, fmaf(C2, t1.x, x0.x)), fmaf(C1, t2.y, fmaf(C2, t1.y, x0.y)));
+    const float2 b1 = make_float2(fmaf(S2, t4.x, S1 * t3.x), fmaf(S2, t4.y, S1 * t3.y));
+    const float2 b2 = make_float2(fmaf(-S1, t4.x, S2 * t3.x), fmaf(-S1, t4.y, S2 * t3.y));
+    x0 = make_float2(x0.x + t1.x + t2.x, x0.y + t1.y + t2.y);
+    x1 = make_float2(a1.x + b1.y, a1.y - b1.x);      // a1 - i*b1
+    x4 = make_float2(a1.x - b1.y, a1.y + b1.x);
+    x2 = make_float2(a2.x + b2.y, a2.y - b2.x);
+    x3 = make_float2(a2.x - b2.y, a2.y + b2.x);
+}
+
+// W25^m = exp(-2 pi i m / 25), m a compile-time constant in [0, 16]
+__device__ __forceinline__ float2 w25(int m) {
+    constexpr float C[17] = {1.f, 0.96858316112863108f, 0.87630668004386358f, 0.72896862742141155f, 0.53582679497899655f,
+                             0.30901699437494745f, 0.062790519529313527f, -0.1873813145857246f, -0.42577929156507272f,
+                             -0.63742398974868975f, -0.80901699437494734f, -0.92977648588825135f, -0.99211470131447776f,
+                             -0.99211470131447788f, -0.92977648588825146f, -0.80901699437494778f, -0.63742398974868952f};
+    constexpr float S[17] = {0.f, 0.24868988716485479f, 0.48175367410171532f, 0.68454710592868862f, 0.84432792550201508f,
+                             0.95105651629515353f, 0.99802672842827156f, 0.98228725072868872f, 0.90482705246601947f,
+                             0.77051324277578925f, 0.58778525229247325f, 0.36812455268467814f, 0.12533323356430454f,
+                             -0.12533323356430429f, -0.36812455268467792f, -0.58778525229247269f, -0.77051324277578936f};
+    return make_float2(C[m], -S[m]);
+}
+
+// 25-point forward DFT in place, radix 5 x 5.  Input z[a] in natural order; output Z[c] is left at
+// z[fft25_pos(c)].
+__host__ __device__ constexpr int fft25_pos(int c) { return 5 * (c % 5) + c / 5; }
+
+__device__ __forceinline__ void fft25(float2 (&z)[25]) {
+    // a = 5*a1 + a2, c = c1 + 5*c2:  W25^(a*c) = W5^(a1*c1) * W25^(a2*c1) * W5^(a2*c2)
+#pragma unroll
+    for (int a2 = 0; a2 < 5; ++a2) dft5(z[a2], z[5 + a2], z[10 + a2], z[15 + a2], z[20 + a2]);    // c1 lands at z[5*c1 + a2]
+#pragma unroll
+    for (int c1 = 1; c1 < 5; ++c1)
+#pragma unroll
+        for (int a2 = 1; a2 < 5; ++a2) z[5 * c1 + a2] = cmul(z[5 * c1 + a2], w25(a2 * c1));
+#pragma unroll
+    for (int c1 = 0; c1 < 5; ++c1) dft5(z[5 * c1], z[5 * c1 + 1], z[5 * c1 + 2], z[5 * c1 + 3], z[5 * c1 + 4]);   // c2 lands at z[5*c1 + c2]
+}
+
+// Position of staged sample i (relative to the wave's first sample) in the LDS staging buffer.  With
+// hop 160 the four frame pairs of a wave start 320 floats apart, i.e. on the same LDS banks; 16
+// floats of padding per 320 samples put them on four different bank groups.  A run of 16 samples
+// that starts at a multiple of 16 never straddles a padding gap.
+template <int HOP>
+__device__ __forceinline__ int stage_pos(int i) {
+    if constexpr (HOP == 160) return i + 16 * (i / 320);
+    else return i;
+}
+
+template <int HOP /* 160: specialised staging layout; 0: any hop <= 160 */, bool VEC /* 16-byte aligned row starts and hop % 4 == 0 */,
+          int S0, int S1, int S2, int S3 /* bins walked by the four mel instruction streams */, bool SPLIT /* last stream: runs split in two halves */>
+__global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Args p) {
+    constexpr int kSteps[kStreams] = {S0, S1, S2, S3};
+    constexpr int kStepOff[kStreams] = {0, S0, S0 + S1, S0 + S1 + S2};
+    constexpr int kTotalSteps = S0 + S1 + S2 + S3;
+    constexpr int kLastStream = S3 > 0 ? 3 : (S2 > 0 ? 2 : (S1 > 0 ? 1 : 0));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* s_tw = reinterpret_cast<float2*>(smem);
+    for (int i = threadIdx.x; i < 25 * 16; i += blockDim.x) s_tw[i] = p.tw[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pr = lane >> 4;      // frame pair within the wave
+    const int b = lane & 15;       // lane within the pair's group
+    char* wave_area = smem + kTwBytes + wave * kWaveBytes;
+    float* stage = reinterpret_cast<float*>(wave_area);
+    float2* tile = reinterpret_cast<float2*>(wave_area + pr * kPairBytes);
+    float* parea = reinterpret_cast<float*>(wave_area);
+
+    // Bin runs of the mel stage may read a few slots that no phase writes (tile padding, staging gaps) with
+    // zero weights; start from zeros so that those slots can never hold a non-finite bit pattern.
+    for (int i = lane; i < kWaveBytes / 16; i += 64) reinterpret_cast<float4*>(wave_area)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    wave_lds_fence();
+
+    const int hop = HOP > 0 ? HOP : p.hop;
+    const int span4 = (7 * hop + kN + 3) & ~3;      // samples staged per pass, rounded up to whole 16-byte pieces
+
+    // ---- per-lane constants, resident for the life of the kernel -----------------------------------
+    float win[25];
+#pragma unroll
+    for (int a = 0; a < 25; ++a) win[a] = p.window[16 * a + b];
+    float wreg[kTotalSteps];
+#pragma unroll
+    for (int s = 0; s < kTotalSteps; ++s) wreg[s] = p.mel_w[s * 64 + lane];
+    const float* pa[kStreams];
+    int dst[kStreams];
+#pragma unroll
+    for (int st = 0; st < kStreams; ++st) {
+        pa[st] = parea + (kSteps[st] > 0 ? p.mel_poff[st * 64 + lane] : 0);
+        dst[st] = kSteps[st] > 0 ? p.mel_dst[st * 64 + lane] : -1;
+    }
+    float none_flag = p.la.none_flag;
+    asm volatile("" : "+v"(none_flag));         // a per-lane value from here on: selects on it stay v_cndmask
+
+    // ---- work distribution: octet = 8 consecutive frames of one row; a block takes kWaves consecutive
+    //      octets per round, so its waves stream one contiguous region and fill whole output lines ------
+    const unsigned opr = (unsigned)(p.frames_valid + 7) >> 3;      // octets per row
+    const unsigned ostride = gridDim.x * kWaves;
+    const unsigned d_row = ostride / opr, d_o = ostride - d_row * opr;
+    const unsigned oct0 = blockIdx.x * kWaves + wave;
+    unsigned row = oct0 / opr, oq = oct0 - row * opr;               // wave-uniform
+    auto advance = [&](unsigned& r, unsigned& o) {
+        r += d_row;
+        o += d_o;
+        if (o >= opr) { o -= opr; r += 1; }
+    };
+
+    // the samples under octet (r, o): lane holds pieces lane, lane+64, ... of 4 consecutive samples
+    float4 pf[kPF];
+    auto fetch = [&](unsigned r, unsigned o) {
+        const float* rp = row_ptr(p.src, r < (unsigned)p.n_rows ? r : 0);
+        const int first = (int)o * 8 * hop + p.shift;
+        const bool interior = first >= 0 && first + span4 <= p.n_samples;     // wave-uniform
+        if (interior) {
+#pragma unroll
+            for (int q = 0; q < kPF; ++q) {
+                const int i = 4 * (lane + 64 * q);
+                const float* sp = rp + first + (i < span4 ? i : 0);
+                if (VEC) pf[q] = *reinterpret_cast<const float4*>(sp);
+                else pf[q] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+            }
+        } else {    // the octet touches an end of the row: padding rule per sample
+#pragma unroll
+            for (int q = 0; q < kPF; ++q) {
+                const int i = 4 * (lane + 64 * q);
+                const int s0 = first + (i < span4 ? i : 0);
+                pf[q] = make_float4(fetch_sample(rp, s0, p.n_samples, p.pad_mode), fetch_sample(rp, s0 + 1, p.n_samples, p.pad_mode),
+                                    fetch_sample(rp, s0 + 2, p.n_samples, p.pad_mode), fetch_sample(rp, s0 + 3, p.n_samples, p.pad_mode));
+            }
+        }
+    };
+    fetch(row, oq);
+
+    // sample n = 16a + b of frames A = 2*pr and B = 2*pr + 1 in the staging buffer
+    const float* st_a = stage + stage_pos<HOP>(2 * pr * hop) + b;
+    const float* st_b = HOP == 160 ? st_a + 160 : stage + (2 * pr + 1) * hop + b;
+    float* const pw_a = parea + (2 * pr) * kPS + kPGuard;
+    float* const pw_b = pw_a + kPS;
+
+    while (row < (unsigned)p.n_rows) {
+        const int t0 = (int)oq * 8;          // first frame of the octet
+        const unsigned cur_row = row;
+
+        // ---- stage the wave's samples -----------------------------------------------------------
+#pragma unroll
+        for (int q = 0; q < kPF; ++q) {
+            const int i = 4 * (lane + 64 * q);
+            if (i < span4) *reinterpret_cast<float4*>(stage + stage_pos<HOP>(i)) = pf[q];
+        }
+        wave_lds_fence();
+        float2 z[25];
+#pragma unroll
+        for (int a = 0; a < 25; ++a) {
+            // hop 160: frame A crosses the padding gap at sample 320 of its pair (a >= 20), frame B at its sample 160 (a >= 10)
+            const int off_a = 16 * a + (HOP == 160 && a >= 20 ? 16 : 0);
+            const int off_b = 16 * a + (HOP == 160 && a >= 10 ? 16 : 0);
+            z[a] = make_float2(win[a] * st_a[off_a], win[a] * st_b[off_b]);
+        }
+        wave_lds_fence();
+
+        // ---- next octet's samples: in flight under the rest of this pass ----------------------------
+        advance(row, oq);
+        fetch(row, oq);
+
+        // ---- 400-point complex FFT, first half: 25-point FFT over a, twiddle, transpose ------------
+        fft25(z);
+#pragma unroll
+        for (int c = 0; c < 25; ++c) {
+            float2 v = z[fft25_pos(c)];
+            if (c > 0) v = cmul(v, s_tw[c * 16 + b]);
+            tile[c * kTileStride + b] = v;
+        }
+        wave_lds_fence();
+        float2 u0[16], u1[16];
+        {
+            const float2* r0 = tile + b * kTileStride;
+            const float2* r1 = tile + (b <= 8 ? 16 + b : 24) * kTileStride;     // lanes 9..15 repeat column 24, result unused
+#pragma unroll
+            for (int bb = 0; bb < 16; ++bb) { u0[bb] = r0[bb]; u1[bb] = r1[bb]; }
+        }
+        wave_lds_fence();
+
+        // ---- second half: 16-point FFTs of columns b and b+16; Z[c + 25 d] parked in natural order ----
+        fft16(u0);
+        fft16(u1);
+#pragma unroll
+        for (int d = 0; d < 16; ++d) tile[b + 25 * d] = u0[fft16_pos(d)];
+        if (b <= 8) {
+#pragma unroll
+            for (int d = 0; d < 16; ++d) tile[16 + b + 25 * d] = u1[fft16_pos(d)];
+        }
+        wave_lds_fence();
+
+        // ---- separate the two real spectra, power ------------------------------------------------
+        float p_a[13], p_b[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            int k = b + 16 * i;
+            if (i == 12) k = k < 200 ? k : 200;
+            int km = 400 - k;
+            if (i == 0) km = k == 0 ? 0 : km;
+            const float2 zk = tile[k];
+            const float2 zm = tile[km];
+            const float2 E = make_float2(zk.x + zm.x, zk.y - zm.y);     // X_A[k]
+            const float2 D = make_float2(zk.x - zm.x, zk.y + zm.y);     // i * X_B[k]
+            p_a[i] = E.x * E.x + E.y * E.y;
+            p_b[i] = D.x * D.x + D.y * D.y;
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            pw_a[b + 16 * i] = p_a[i];
+            pw_b[b + 16 * i] = p_b[i];
+        }
+        if (b <= 8) {
+            pw_a[192 + b] = p_a[12];
+            pw_b[192 + b] = p_b[12];
+        }
+        wave_lds_fence();
+
+        // ---- banded mel on the matrix pipe, log, affine, store ---------------------------------------
+        float lmax = -INFINITY;
+#pragma unroll
+        for (int st = 0; st < kStreams; ++st) {
+            if (kSteps[st] == 0) continue;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < kSteps[st]; ++s)
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(pa[st][s], wreg[kStepOff[st] + s], acc, 0, 0, 0);
+            if (SPLIT && st == kLastStream) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] += __shfl_xor(acc[i], 32);
+            }
+            // lane = 4*blk + j holds filter j of the block's unit for its 4 frames in registers 0..3
+            const int d = dst[st];
+            const int m = d & 0xffff;
+            const int tf = t0 + 4 * (d >> 16);          // first of the lane's 4 frames
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = apply_log_affine(acc[i], p.la, none_flag);
+            if (d >= 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lmax = tf + i < p.frames_valid ? fmaxf(lmax, v[i]) : lmax;
+                if (p.layout == MMFE_LAYOUT_FEAT_MAJOR) {
+                    float* o = p.out + ((int64_t)cur_row * p.n_mel + m) * p.out_frames + tf;
+                    if (p.vec_store && tf + 4 <= p.frames_valid) {
+                        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (tf + i < p.frames_valid) o[i] = v[i];
+                    }
+                } else {
+                    float* o = p.out + ((int64_t)cur_row * p.out_frames + tf) * p.n_mel + m;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (tf + i < p.frames_valid) o[(int64_t)i * p.n_mel] = v[i];
+                }
+            }
+        }
+        if (p.rowmax != nullptr) {
+            for (int off = 32; off > 0; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+            if (lane == 0 && lmax > -INFINITY) atomicMax(p.rowmax + cur_row, float_to_ordered(lmax));
+        }
+        wave_lds_fence();
+    }
+}
+
+// instantiated stream shapes (bins walked per stream, split flag), tightest first
+struct MelShape { int s[kStreams]; bool split; };
+constexpr MelShape kShapes[] = {
+    {{5, 19, 17, 0}, true},       // 80 Slaney bands on 201 bins (16 kHz)
+    {{8, 20, 20, 0}, true},       // 80 kaldi bands
+    {{4, 8, 12, 24}, false},      // 128 bands
+    {{12, 44, 0, 0}, false},      // 64 bands
+    {{36, 32, 0, 0}, true},       // 40 bands
+};
+
+template <int HOP, bool VEC, int S0, int S1, int S2, int S3, bool SPLIT>
+int launch_variant(const Rfft400Args& a, int64_t octets, hipStream_t stream) {
+    const void* fn = reinterpret_cast<const void*>(&rfft400_kernel<HOP, VEC, S0, S1, S2, S3, SPLIT>);
+    const size_t lds = kTwBytes + (size_t)kWaves * kWaveBytes;
+    static unsigned long long done_mask = 0;
+    int dev = 0, cus = 256;
+    MMFE_HIP_CHECK(hipGetDevice(&dev));
+    if (!(done_mask >> (dev & 63) & 1ull)) {
+        MMFE_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        done_mask |= 1ull << (dev & 63);
+    }
+    MMFE_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    int blocks_per_cu = 1;
+    MMFE_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, 64 * kWaves, lds));
+    const int64_t want = (octets + kWaves - 1) / kWaves;
+    const int grid = (int)std::min<int64_t>(want, (int64_t)cus * std::max(1, blocks_per_cu));
+    hipLaunchKernelGGL((rfft400_kernel<HOP, VEC, S0, S1, S2, S3, SPLIT>), dim3(grid), dim3(64 * kWaves), lds, stream, a);
+    MMFE_HIP_CHECK(hipGetLastError());
+    return MMFE_OK;
+}
+
+}  // namespace
+
+bool rfft400_supports(const mmfe_spec& s) {
+    if (const char* f = std::getenv("MMFE_FORCE_GENERIC")) {
+        if (std::string(f) == "1") return false;
+    }
+    return s.n_fft == kN && s.n_mel > 0 && s.n_mel <= 128 && s.power == 2 && s.spec_scale == 1.0f && !s.window_f64 &&
+           !s.remove_dc && s.preemph == 0.f && s.hop >= 1 && s.hop <= kMaxHop &&
+           (s.frames_mode == MMFE_FRAMES_CENTER || s.frames_mode == MMFE_FRAMES_SNIP);
+}
+
+// Builds the twiddle / window tables and the mel instruction streams.  Returns MMFE_EINVAL (with the
+// error text set) when the filter bank fits none of the instantiated stream shapes; the caller then
+// falls back to the any-length kernel.
+int rfft400_prepare(Plan& plan) {
+    const mmfe_spec& s = plan.spec;
+    if (!rfft400_supports(s)) { set_error("rfft400: unsupported spec"); return MMFE_EINVAL; }
+    for (int m = 0; m < s.n_mel; ++m) {
+        const int st = plan.band_start[m], len = plan.band_len[m];
+        if (len > 0 && (st < 0 || st + len > kBins)) {
+            set_error("rfft400: mel band %d = [%d, %d) leaves the 201-bin spectrum", m, st, st + len);
+            return MMFE_EINVAL;
+        }
+    }
+    // ---- (filter block, frame group) units in order of frequency, 16 per stream ---------------------
+    const int nfb = (s.n_mel + 3) / 4;
+    const int units = 2 * nfb;
+    const int n_streams = (units + 15) / 16;
+    std::vector<int> kmin(nfb, 0), run(nfb, 0);
+    for (int fb = 0; fb < nfb; ++fb) {
+        int lo = 1 << 30, hi = -1;
+        for (int j = 0; j < 4; ++j) {
+            const int m = 4 * fb + j;
+            if (m >= s.n_mel || plan.band_len[m] == 0) continue;
+            lo = std::min(lo, (int)plan.band_start[m]);
+            hi = std::max(hi, (int)(plan.band_start[m] + plan.band_len[m] - 1));
+        }
+        if (hi >= 0) { kmin[fb] = lo; run[fb] = hi - lo + 1; }
+    }
+    const int last_units = units - 16 * (n_streams - 1);
+    const bool split = last_units <= 8;
+    int steps[kStreams] = {0, 0, 0, 0};
+    for (int u = 0; u < units; ++u) {
+        const int st = u / 16, fb = u >> 1;
+        const int need = (split && st == n_streams - 1) ? (run[fb] + 1) / 2 : run[fb];
+        steps[st] = std::max(steps[st], std::max(need, 1));
+    }
+    int pick = -1;
+    for (size_t i = 0; i < sizeof(kShapes) / sizeof(kShapes[0]); ++i) {
+        bool ok = kShapes[i].split == split;
+        for (int st = 0; st < kStreams; ++st) {
+            if ((kShapes[i].s[st] > 0) != (steps[st] > 0) || kShapes[i].s[st] < steps[st]) ok = false;
+        }
+        if (ok) { pick = (int)i; break; }
+    }
+    if (pick < 0) {
+        set_error("rfft400: no kernel variant for mel stream shape (%d, %d, %d, %d)%s", steps[0], steps[1], steps[2], steps[3],
+                  split ? " split" : "");
+        return MMFE_EINVAL;
+    }
+    const MelShape& shape = kShapes[pick];
+    int step_off[kStreams + 1] = {0, 0, 0, 0, 0};
+    for (int st = 0; st < kStreams; ++st) step_off[st + 1] = step_off[st] + shape.s[st];
+    std::vector<int> boff(s.n_mel + 1, 0);
+    for (int m = 0; m < s.n_mel; ++m) boff[m + 1] = boff[m] + plan.band_len[m];
+
+    std::vector<int32_t> poff(kStreams * 64, kPGuard), dst(kStreams * 64, -1);
+    std::vector<float> w((size_t)std::max(step_off[kStreams], 1) * 64, 0.f);
+    for (int st = 0; st < n_streams; ++st) {
+        const bool split_here = split && st == n_streams - 1;
+        for (int blk = 0; blk < 16; ++blk) {
+            const int part = split_here ? blk / 8 : 0;
+            const int u = 16 * st + (split_here ? blk % 8 : blk);
+            if (u >= units) continue;
+            const int fb = u >> 1, g = u & 1;
+            // a split stream walks [kmin, kmin + S) in blocks 0..7 and [kmin + S, kmin + 2S) in blocks 8..15
+            const int ks = kmin[fb] + part * shape.s[st];
+            for (int j = 0; j < 4; ++j) {
+                const int lane = 4 * blk + j;
+                poff[st * 64 + lane] = (4 * g + j) * kPS + kPGuard + ks;      // operand A: frame 4g+j of the octet
+                const int m = 4 * fb + j;                                      // operand B / result: filter m
+                if (m >= s.n_mel) continue;
+                if (part == 0) dst[st * 64 + lane] = m | (g << 16);
+                for (int sp = 0; sp < shape.s[st]; ++sp) {
+                    const int rel = ks + sp - plan.band_start[m];
+                    if (rel >= 0 && rel < plan.band_len[m]) w[(size_t)(step_off[st] + sp) * 64 + lane] = plan.band_weights[boff[m] + rel];
+                }
+            }
+        }
+    }
+    plan.r400_shape = pick;
+    std::vector<float> win(kN, 0.f);
+    for (int i = 0; i < s.win_len; ++i) win[s.win_off + i] = 0.5f * plan.window[i];
+    std::vector<float> tw(2 * 25 * 16);
+    const double pi = 3.14159265358979323846;
+    for (int c = 0; c < 25; ++c)
+        for (int b = 0; b < 16; ++b) {
+            tw[2 * (c * 16 + b)] = (float)std::cos(2.0 * pi * (b * c) / 400.0);
+            tw[2 * (c * 16 + b) + 1] = (float)-std::sin(2.0 * pi * (b * c) / 400.0);
+        }
+    int rc;
+    if ((rc = upload(&plan.d_window, win))) return rc;
+    if ((rc = upload(&plan.d_tw_a, tw))) return rc;
+    if ((rc = upload(&plan.d_mel4_kstart, poff))) return rc;
+    if ((rc = upload(&plan.d_r400_dst, dst))) return rc;
+    if ((rc = upload(&plan.d_mel4_w, w))) return rc;
+    return MMFE_OK;
+}
+
+int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames_natural,
+                   int64_t out_frames, float* out, hipStream_t stream) {
+    const mmfe_spec& s = plan.spec;
+    const int64_t frames_valid = std::min(n_frames_natural, out_frames);
+    if (n_rows <= 0 || frames_valid <= 0) return MMFE_OK;
+    const int64_t octets = n_rows * ((frames_valid + 7) / 8);
+    if (octets >= (int64_t)1 << 31 || n_rows >= (int64_t)1 << 31 || n_samples >= (int64_t)1 << 30) {
+        set_error("rfft400: batch too large for one launch");
+        return MMFE_EINVAL;
+    }
+    const bool clamp = s.clamp_below_max > 0.f;
+    Rfft400Args a{};
+    a.src = src;
+    a.out = out;
+    a.rowmax = nullptr;
+    a.n_rows = (int)n_rows;
+    a.n_samples = (int)n_samples;
+    a.frames_valid = (int)frames_valid;
+    a.out_frames = (int)out_frames;
+    a.hop = s.hop;
+    a.shift = s.frames_mode == MMFE_FRAMES_CENTER ? -kN / 2 : -s.win_off;
+    a.pad_mode = s.pad_mode;
+    a.n_mel = s.n_mel;
+    a.layout = s.layout;
+    a.vec_store = (out_frames % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 1 : 0;
+    a.la = make_log_affine(s, clamp);      // with the clamp, shift and scale follow in the second pass
+    a.window = plan.d_window;
+    a.tw = reinterpret_cast<const float2*>(plan.d_tw_a);
+    a.mel_poff = plan.d_mel4_kstart;
+    a.mel_dst = plan.d_r400_dst;
+    a.mel_w = plan.d_mel4_w;
+    if (clamp) {
+        int rc = rowmax_init_launch(plan, n_rows, stream);
+        if (rc) return rc;
+        a.rowmax = reinterpret_cast<int*>(plan.d_rowmax);
+    }
+    const bool vec = s.hop % 4 == 0 && a.shift % 4 == 0 && src.offsets == nullptr && src.stride % 4 == 0 && reinterpret_cast<uintptr_t>(src.base) % 16 == 0;
+    int rc = MMFE_EINVAL;
+    bool found = false;
+#define MMFE_R400_SHAPE(IDX, A, B, C, D, SP)                                                                     \
+    if (plan.r400_shape == IDX) {                                                                                \
+        found = true;                                                                                            \
+        if (s.hop == 160 && vec) rc = launch_variant<160, true, A, B, C, D, SP>(a, octets, stream);              \
+        else if (vec) rc = launch_variant<0, true, A, B, C, D, SP>(a, octets, stream);                           \
+        else rc = launch_variant<0, false, A, B, C, D, SP>(a, octets, stream);                                   \
+    }
+    MMFE_R400_SHAPE(0, 5, 19, 17, 0, true)
+    MMFE_R400_SHAPE(1, 8, 20, 20, 0, true)
+    MMFE_R400_SHAPE(2, 4, 8, 12, 24, false)
+    MMFE_R400_SHAPE(3, 12, 44, 0, 0, false)
+    MMFE_R400_SHAPE(4, 36, 32, 0, 0, true)
+#undef MMFE_R400_SHAPE
+    if (!found) { set_error("rfft400: plan has no kernel variant"); return MMFE_EINVAL; }
+    if (rc) return rc;
+    if (clamp) rc = clamp_affine_launch(plan, out, n_rows, out_frames * (int64_t)s.n_mel, stream);
+    return rc;
+}
+
+}  // namespace mmfe

@@ -15,6 +15,12 @@ from . import _native as N
 
 _plans: Dict[Hashable, N.Plan] = {}
 _plans_lock = threading.Lock()
+_last_kernel = "none"
+
+
+def last_kernel() -> str:
+    """Kernel family ("fbank512", "rfft400", "dftgen", ...) that served the most recent run_rows call (diagnostic)."""
+    return _last_kernel
 
 
 def require_gpu() -> None:
@@ -74,6 +80,8 @@ def run_rows(plan: N.Plan, x: torch.Tensor, out: torch.Tensor = None) -> torch.T
         return out
     if x.device.index != plan.device:
         raise ValueError(f"tensor on {x.device} but plan on cuda:{plan.device}")
+    global _last_kernel
+    _last_kernel = plan.kernel
     stream = torch.cuda.current_stream(x.device).cuda_stream
     stride = x.stride(0) if rows > 1 else max(x.stride(0), n)
     plan.run_ptr(x.data_ptr(), stride, rows, n, out.data_ptr(), stream)

@@ -276,18 +276,20 @@ def slaney_mel_filters(n_freqs: int, n_mels: int, sr: float, fmin: float = 0.0, 
     return fb
 
 
-def whisper_logmel(wave: np.ndarray, n_fft: int = 400, hop: int = 160, n_mels: int = 80, sr: int = 16000) -> np.ndarray:
+def whisper_logmel(wave: np.ndarray, n_fft: int = 400, hop: int = 160, n_mels: int = 80, sr: int = 16000,
+                   compute_dtype=np.float64) -> np.ndarray:
     """(n,) -> (n_mels, n // hop): periodic Hann, centre reflect padding, |X|^2, Slaney mel,
-    log10(max(., 1e-10)), last frame dropped, clamp to (max - 8), (x + 4) / 4.  fp64 maths,
+    log10(max(., 1e-10)), last frame dropped, clamp to (max - 8), (x + 4) / 4.  Maths in
+    `compute_dtype` (float64 like the numpy feature extractor, or float32 like a torch.stft one),
     fp32 result."""
-    y = np.asarray(wave, dtype=np.float64)
-    w = scipy.signal.get_window("hann", n_fft, fftbins=True)
+    y = np.asarray(wave, dtype=compute_dtype)
+    w = scipy.signal.get_window("hann", n_fft, fftbins=True).astype(compute_dtype)
     yp = np.pad(y, n_fft // 2, mode="reflect")
     n_frames = 1 + (yp.shape[0] - n_fft) // hop
     idx = hop * np.arange(n_frames)[:, None] + np.arange(n_fft)[None, :]
-    spec = np.abs(np.fft.rfft(yp[idx] * w, axis=-1)) ** 2           # (frames, bins)
-    fb = slaney_mel_filters(1 + n_fft // 2, n_mels, sr)
-    mel = np.maximum(1e-10, spec @ fb)
+    spec = np.abs(np.fft.rfft(yp[idx] * w, axis=-1)) ** 2           # (frames, bins); numpy keeps float32 input in float32
+    fb = slaney_mel_filters(1 + n_fft // 2, n_mels, sr).astype(compute_dtype)
+    mel = np.maximum(compute_dtype(1e-10), spec @ fb)
     lg = np.log10(mel).T[:, :-1]
     lg = np.maximum(lg, lg.max() - 8.0)
     return ((lg + 4.0) / 4.0).astype(np.float32)

@@ -52,12 +52,12 @@ def main():
                           "bytes_per_clip": per, "GB/s": per * B / (avg * 1e-3) / 1e9, "frac_of_8TBs": per * B / (avg * 1e-3) / 8e12}))
         del x, out
     if "logmel" in which:
-        B = 256
+        B = 1024
         x = (0.1 * torch.randn(B, 480000, device=dev, generator=g)).clamp_(-1, 1)
         out = torch.empty(B, 80, 3000, device=dev)
-        avg, mn = timeit(lambda: mm.logmel.log_mel_spectrogram(x, out=out), max(3, iters // 4))
+        avg, mn = timeit(lambda: mm.logmel.log_mel_spectrogram(x, out=out), iters)
         per = 480000 * 4 + 80 * 3000 * 4
-        print(json.dumps({"config": "long-utterance log-mel (256, 480000) -> (256, 80, 3000), n_fft 400", "utt_per_s": B / (avg * 1e-3), "ms": avg,
+        print(json.dumps({"config": "long-utterance log-mel (1024, 480000) -> (1024, 80, 3000), n_fft 400, kernel " + mm.plans.last_kernel(), "utt_per_s": B / (avg * 1e-3), "ms": avg,
                           "min_ms": mn, "bytes_per_utt": per, "GB/s": per * B / (avg * 1e-3) / 1e9, "frac_of_8TBs": per * B / (avg * 1e-3) / 8e12}))
 
 

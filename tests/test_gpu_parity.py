@@ -307,14 +307,102 @@ def test_frame_signal(mm, O, shape, fl, hop):
         mm.frame_signal(s, fl, hop, torch.ones(fl + 1))
 
 
-def test_long_utterance_logmel(mm, O):
-    x = np.stack([synth("noise0.1", 480000, 99), synth("sine+noise", 480000, 100)])
+@pytest.mark.parametrize("precision", ["float32", "float64"])
+def test_long_utterance_logmel(mm, O, precision):
+    """30 s utterances, n_fft 400 / hop 160 / 80 mel: the radix kernel (float32) and the any-length kernel with
+    float64 accumulation, both against the float64 CPU restatement.  Tolerance 1e-4 abs on the normalised
+    log-mel; the float32 CPU evaluation of the same formula sits within 2e-5 of the float64 one."""
+    x = np.stack([synth("noise0.1", 480000, 99), synth("sine+noise", 480000, 100), synth("quiet", 480000, 101)])
     ref = np.stack([O.whisper_logmel(c) for c in x])
-    got = mm.logmel.log_mel_spectrogram(torch.from_numpy(x).cuda()).cpu().numpy()
-    assert got.shape == ref.shape == (2, 80, 3000)
+    got = mm.logmel.log_mel_spectrogram(torch.from_numpy(x).cuda(), precision=precision).cpu().numpy()
+    assert got.shape == ref.shape == (3, 80, 3000)
+    assert mm.plans.last_kernel() == ("rfft400" if precision == "float32" else "dftgen")
     mx, p999 = _stats(got - ref)
-    print("logmel max", mx, p999)
+    print("logmel", precision, "max", mx, "p99.9", p999)
     assert mx <= 1e-4
+
+
+@pytest.mark.parametrize("n", [160, 161, 399, 400, 401, 1279, 1280, 1281, 4000, 16000, 48001])
+def test_logmel_lengths(mm, O, n):
+    """Ragged utterance lengths: partial last octets, rows shorter than one window (reflection wraps more than once)."""
+    x = synth("noise0.1", n, 300 + n)
+    ref = O.whisper_logmel(x)
+    got = mm.logmel.log_mel_spectrogram(torch.from_numpy(x)[None].cuda()).cpu().numpy()[0]
+    assert got.shape == ref.shape == (80, n // 160)
+    mx, _ = _stats(got - ref)
+    assert mx <= 1e-4
+
+
+@pytest.mark.parametrize("hop,off", [(160, 0), (160, 1), (100, 0), (150, 0), (128, 2), (7, 0)])
+def test_logmel_hops_and_alignment(mm, O, hop, off):
+    """Other hops (generic staging layout, scalar loads when hop % 4 != 0) and rows that start off a 16-byte boundary."""
+    n = 24000
+    base = np.stack([synth("noise0.1", n + 4, 11), synth("uniform", n + 4, 12), synth("sine+noise", n + 4, 13)])
+    x = base[:, off:off + n]
+    ref = np.stack([O.whisper_logmel(c, hop=hop) for c in x])
+    xg = torch.from_numpy(base).cuda()[:, off:off + n]
+    got = mm.logmel.log_mel_spectrogram(xg, hop_length=hop).cpu().numpy()
+    assert got.shape == ref.shape
+    assert mm.plans.last_kernel() == "rfft400"
+    mx, _ = _stats(got - ref)
+    print("hop", hop, "off", off, "max", mx)
+    assert mx <= 1e-4
+
+
+def test_logmel_kernels_agree(mm):
+    """The radix kernel and the any-length float64 kernel serve the same plan parameters: same shapes, same values
+    to float32 FFT accuracy, on a batch large enough to wrap the persistent grid several times."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = (0.1 * torch.randn(600, 16000, device="cuda", generator=g)).clamp_(-1, 1)
+    a = mm.logmel.log_mel_spectrogram(x, precision="float32")
+    b = mm.logmel.log_mel_spectrogram(x, precision="float64")
+    assert a.shape == b.shape == (600, 80, 100)
+    assert (a - b).abs().max().item() <= 1e-4
+    # equal rows give bit-identical features wherever they sit in the batch
+    y = x[:3].repeat(200, 1)
+    c = mm.logmel.log_mel_spectrogram(y)
+    assert torch.equal(c.view(200, 3, 80, 100), a[:3].unsqueeze(0).expand(200, -1, -1, -1))
+
+
+def test_rfft400_time_major_no_clamp(mm):
+    """Direct plan: centred zero-padded framing, 128 Slaney bands, ln(x + eps), time-major output, no clamp pass."""
+    from multi_modal_amd import _native as N, melbank
+    n, hop = 20000, 160
+    x = np.stack([synth("noise0.1", n, 21), synth("uniform", n, 22)])
+    fb = melbank.slaney_mel_filters(201, 128, 16000).astype(np.float32)
+    bs, bl, bw = melbank.dense_to_bands(fb)
+    win = melbank.periodic_hann(400).astype(np.float32)
+    spec = N.make_spec(kind=N.KIND_LOGSPEC, n_fft=400, win_len=400, win_off=0, hop=hop, pad_mode=N.PAD_ZERO,
+                       frames_mode=N.FRAMES_CENTER, n_mel=128, power=2, log_kind=N.LOG_LN_ADD, log_floor=1e-6,
+                       out_shift=1.5, out_scale=0.5, layout=N.LAYOUT_TIME_MAJOR)
+    plan = N.Plan(spec, win, bs, bl, bw, device=0)
+    assert plan.kernel == "rfft400"
+    xg = torch.from_numpy(x).cuda()
+    frames = 1 + n // hop
+    out = torch.empty(2, frames, 128, device="cuda")
+    plan.run_ptr(xg.data_ptr(), xg.stride(0), 2, n, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    xp = np.pad(x.astype(np.float64), ((0, 0), (200, 200)))
+    idx = hop * np.arange(frames)[:, None] + np.arange(400)[None, :]
+    P = np.abs(np.fft.rfft(xp[:, idx] * win.astype(np.float64), axis=-1)) ** 2
+    ref = (np.log(P @ fb.T.astype(np.float64) + 1e-6) + 1.5) * 0.5
+    mx, _ = _stats(out.cpu().numpy() - ref)
+    print("time-major ln_add max", mx)
+    assert mx <= 1e-4
+
+
+def test_fbank_n400_radix(mm, O):
+    """kaldi fbank without power-of-two rounding, DC removal or pre-emphasis: 400-point spectrum, snip-edge framing."""
+    x = synth("noise0.1", 48000, 31)
+    kw = dict(num_mel_bins=80, round_to_power_of_two=False, remove_dc_offset=False, preemphasis_coefficient=0.0,
+              window_type="hanning")
+    ref = O.kaldi_fbank(torch.from_numpy(x)[None], sample_frequency=16000, **kw).numpy()
+    got = mm.fbank(torch.from_numpy(x)[None].cuda(), sample_frequency=16000, **kw).cpu().numpy()
+    assert got.shape == ref.shape
+    assert mm.plans.last_kernel() == "rfft400"
+    mx, p999 = _stats(got - ref)
+    print("fbank n_fft=400 max", mx, "p99.9", p999)
+    assert p999 <= 1e-4 and mx <= 2e-3
 
 
 def test_cal_norm(mm):
