@@ -26,6 +26,7 @@ namespace {
 
 constexpr int FR = 16;           // frames per block
 constexpr int kThreads = 256;
+static_assert(FR == 4 * (kThreads / 64), "the DFT loop gives each of the block's waves 4 frames");
 
 struct DftArgs {
     RowSource src;
@@ -69,12 +70,25 @@ __device__ __forceinline__ float dft_log(float x, int kind, float floor_, float 
 
 __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double2* s_tw = reinterpret_cast<double2*>(smem);                     // n_fft
-    double* s_u = reinterpret_cast<double*>(s_tw + p.n_fft);              // win_len * FR, [tap][frame], float64
-    float* s_p = reinterpret_cast<float*>(s_u + p.win_len * FR);                                     // FR * (n_bins + 1), [frame][bin]
+    double2* s_tw = reinterpret_cast<double2*>(smem);                     // 2*n_fft half-step twiddles
+    double* s_u = reinterpret_cast<double*>(s_tw + 2 * p.n_fft);          // win_len * FR, [tap][frame], float64
+    float* s_p = reinterpret_cast<float*>(s_u + (p.win_len + 1) * FR);                                     // FR * (n_bins + 1), [frame][bin]
     const int pstride = p.n_bins + 1;
 
-    for (int i = threadIdx.x; i < p.n_fft; i += kThreads) s_tw[i] = p.tw[i];
+    for (int i = threadIdx.x; i < 2 * p.n_fft; i += kThreads) s_tw[i] = p.tw[i];
+    if (threadIdx.x < FR) s_u[p.win_len * FR + threadIdx.x] = 0.0;        // row of zeros behind the taps
+    // Only |X[k]| is ever used, and it does not change when the DFT is taken about the centre of the window
+    // instead of tap 0.  About the centre the cosine is even and the sine is odd, so with
+    //   e[i] = u[hi_i] + u[lo_i],  o[i] = u[hi_i] - u[lo_i]   (taps mirrored about the centre, distance m_i)
+    // the spectrum is  sum_i e[i] cos(2 pi k m_i / N)  -  i * sum_i o[i] sin(2 pi k m_i / N):
+    // half the multiply-adds of the plain sum.  m_i = i + 1/2 for an even window length, i for an odd one;
+    // the twiddle table holds half steps exp(-2 pi i n / 2N), indexed with k * (2 m_i) mod 2N.
+    const int L = p.win_len;
+    const int H = (L + 1) >> 1;              // mirrored tap pairs (the centre tap of an odd window pairs with itself)
+    const int odd = L & 1;
+    const int hi0 = L >> 1;                  // first tap at or above the centre
+    const int lo0 = (L - 1) >> 1;            // first tap at or below the centre (== hi0 when L is odd)
+    const int two_n = 2 * p.n_fft;
 
     const int blocks_per_row = (p.frames_valid + FR - 1) / FR;
     const int64_t n_work = (int64_t)p.n_rows * blocks_per_row;
@@ -86,22 +100,61 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
         const float* rp = row_ptr(p.src, row);
 
         __syncthreads();   // previous work item is done with s_u / s_p (and s_tw is loaded)
-        // ---- stage windowed frames: u[j][f] ---------------------------------------------------
-        for (int i = threadIdx.x; i < p.win_len * FR; i += kThreads) {
-            const int f = i / p.win_len;          // consecutive threads walk consecutive taps: coalesced reads
-            const int j = i - f * p.win_len;
-            double v = 0.0;
-            if (f < nfr) {
-                const int base = (t0 + f) * p.hop + p.centre_shift;
-                float x = fetch_sample(rp, base + j, p.n_samples, p.pad_mode);
-                if (p.preemph != 0.f && !p.remove_dc) {
-                    const float prev = fetch_sample(rp, base + (j > 0 ? j - 1 : 0), p.n_samples, p.pad_mode);
-                    x = x - p.preemph * prev;
+        // ---- stage windowed frames: u[j][f].  16 consecutive threads take one tap of the 16 frames, so a wave
+        //      writes 4 whole rows of the [tap][frame] array (512 contiguous bytes, no LDS bank conflict); its
+        //      global reads are 16 runs of 4 consecutive samples, which the overlapping frames keep in L1/L2 ----
+        {
+            const int f = threadIdx.x & (FR - 1);
+            const int base = (t0 + f) * p.hop + p.centre_shift;
+            constexpr int kRows = kThreads / FR;       // taps staged per sweep of the block
+            // Blocks whose 16 frames lie inside the row (all but the first and last few of a row) read without
+            // any padding test, 8 taps per thread in flight at once; a sweep that waits for one load at a
+            // time would leave the block idle for a memory round trip per 16 taps.
+            const int lo_s = t0 * p.hop + p.centre_shift - 1;                                  // incl. the pre-emphasis neighbour
+            const int hi_s = (t0 + FR - 1) * p.hop + p.centre_shift + p.win_len;
+            const bool interior = nfr == FR && lo_s >= 0 && hi_s <= p.n_samples;              // block-uniform
+            if (interior) {
+                const float* fp = rp + base;
+                const bool pre = p.preemph != 0.f && !p.remove_dc;
+#ifdef MMFE_DFT_ABL_NOSTAGE
+                for (int j0 = threadIdx.x / FR; j0 < (p.n_rows < 0 ? p.win_len : 8 * kRows); j0 += 8 * kRows) {
+#else
+                for (int j0 = threadIdx.x / FR; j0 < p.win_len; j0 += 8 * kRows) {
+#endif
+                    float x[8], xp[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = j0 + u * kRows;
+                        const int jc = j < p.win_len ? j : 0;
+                        x[u] = fp[jc];
+                        xp[u] = pre ? fp[jc > 0 ? jc - 1 : 0] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = j0 + u * kRows;
+                        if (j < p.win_len) {
+                            const float xv = pre ? x[u] - p.preemph * xp[u] : x[u];
+                            double v = xv;
+                            if (!p.remove_dc) v *= p.window[j];      // float64 window x float32 sample, rounded in float64
+                            s_u[j * FR + f] = v;
+                        }
+                    }
                 }
-                v = x;
-                if (!p.remove_dc) v *= p.window[j];      // float64 window x float32 sample, rounded in float64
+            } else {
+                for (int j = threadIdx.x / FR; j < p.win_len; j += kRows) {
+                    double v = 0.0;
+                    if (f < nfr) {
+                        float x = fetch_sample(rp, base + j, p.n_samples, p.pad_mode);
+                        if (p.preemph != 0.f && !p.remove_dc) {
+                            const float prev = fetch_sample(rp, base + (j > 0 ? j - 1 : 0), p.n_samples, p.pad_mode);
+                            x = x - p.preemph * prev;
+                        }
+                        v = x;
+                        if (!p.remove_dc) v *= p.window[j];
+                    }
+                    s_u[j * FR + f] = v;
+                }
             }
-            s_u[j * FR + f] = v;
         }
         __syncthreads();
         if (p.remove_dc) {
@@ -123,33 +176,73 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
             __syncthreads();
         }
 
-        // ---- direct DFT: thread k owns bin k (and k + 256, ...) for all FR frames.  Products and sums
-        //      are float64, the arithmetic type of the librosa path (fp64 window x fp32 frame, fp64
-        //      FFT, result rounded to complex64); gfx950 issues v_fma_f64 at the fp32 FMA rate. -------
-        for (int k = threadIdx.x; k < p.n_bins; k += kThreads) {
-            double re[FR], im[FR];
+        // ---- fold the windowed taps about the window centre: e at the upper tap's slot, o at the lower one's -----
+        for (int i = threadIdx.x; i < (H - odd) * FR; i += kThreads) {
+            const int q = i / FR + odd;          // pair index (the self-paired centre tap of an odd window is left as it is)
+            const int f = i - (i / FR) * FR;
+            const double a = s_u[(lo0 - q) * FR + f], b = s_u[(hi0 + q) * FR + f];
+            s_u[(hi0 + q) * FR + f] = b + a;
+            s_u[(lo0 - q) * FR + f] = b - a;
+        }
+        __syncthreads();
+
+        // ---- direct DFT about the window centre.  Register blocking: wave w owns frames 4w..4w+3, lane l owns
+        //      bins l, l+64, l+128, l+192 (of each group of 256 bins): 32 float64 accumulators per thread, and per
+        //      tap pair 4 broadcast reads of e/o plus 4 twiddle reads feed 32 multiply-adds, so the LDS pipe
+        //      keeps pace with the float64 FMA pipe.  Products and sums are float64, the arithmetic type of the
+        //      librosa path (fp64 window x fp32 frame, fp64 FFT, result rounded to complex64); gfx950 issues
+        //      v_fma_f64 at the fp32 FMA rate. -------------------------------------------------------------
+        const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+        for (int kb = 0; kb < p.n_bins; kb += 256) {
+            double re[4][4], im[4][4];
+            // twiddle cursors are byte offsets into s_tw, which sits at LDS offset 0; min(a, a - span) in unsigned
+            // arithmetic is the wrap-around (a - span underflows to a huge value while a < span)
+            unsigned tw_at[4], tw_step[4];
+            const unsigned tw_span = (unsigned)two_n * 16u;
 #pragma unroll
-            for (int f = 0; f < FR; ++f) { re[f] = 0.0; im[f] = 0.0; }
-            int idx = (int)(((int64_t)p.win_off * k) % p.n_fft);
-            for (int j = 0; j < p.win_len; ++j) {
-                const double2 w = s_tw[idx];
-                idx += k;
-                if (idx >= p.n_fft) idx -= p.n_fft;
-                const double2* up = reinterpret_cast<const double2*>(s_u + j * FR);
+            for (int j = 0; j < 4; ++j) {
+                const int k = kb + ln + 64 * j;
+                const int kk = k < p.n_bins ? k : 0;        // lanes past the last bin compute bin 0 and drop it
+                tw_step[j] = (unsigned)((2 * kk) % two_n) * 16u;
+                tw_at[j] = odd ? 0u : (unsigned)(kk % two_n) * 16u;      // k * (2 m_0) mod 2N
 #pragma unroll
-                for (int q = 0; q < FR / 2; ++q) {
-                    const double2 u = up[q];
-                    re[2 * q + 0] = fma(u.x, w.x, re[2 * q + 0]); im[2 * q + 0] = fma(u.x, w.y, im[2 * q + 0]);
-                    re[2 * q + 1] = fma(u.y, w.x, re[2 * q + 1]); im[2 * q + 1] = fma(u.y, w.y, im[2 * q + 1]);
+                for (int f = 0; f < 4; ++f) { re[j][f] = 0.0; im[j][f] = 0.0; }
+            }
+#ifdef MMFE_DFT_ABL_NOLOOP
+            for (int i = 0; i < (p.n_rows < 0 ? H : 1); ++i) {
+#else
+            for (int i = 0; i < H; ++i) {
+#endif
+                // the centre tap of an odd window pairs with itself: its odd part is the row of zeros behind the taps
+                const double2* ep = reinterpret_cast<const double2*>(s_u + (hi0 + i) * FR + 4 * wv);
+                const double2* op = reinterpret_cast<const double2*>(s_u + ((odd && i == 0) ? L : lo0 - i) * FR + 4 * wv);
+                const double2 e01 = ep[0], e23 = ep[1], o01 = op[0], o23 = op[1];
+                const double e[4] = {e01.x, e01.y, e23.x, e23.y};
+                const double o[4] = {o01.x, o01.y, o23.x, o23.y};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double2 w = *reinterpret_cast<const double2*>(smem + tw_at[j]);
+                    tw_at[j] += tw_step[j];
+                    tw_at[j] = min(tw_at[j], tw_at[j] - tw_span);
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        re[j][f] = fma(e[f], w.x, re[j][f]);
+                        im[j][f] = fma(o[f], w.y, im[j][f]);
+                    }
                 }
             }
 #pragma unroll
-            for (int f = 0; f < FR; ++f) {
-                // complex64 rounding of the spectrum, then fp32 |.|^2 like the reference's numpy expression
-                const float xr = (float)(re[f] * (double)p.spec_scale), xi = (float)(im[f] * (double)p.spec_scale);
-                float v = xr * xr + xi * xi;
-                if (p.power == 1) v = sqrtf(v);
-                s_p[f * pstride + k] = v;
+            for (int j = 0; j < 4; ++j) {
+                const int k = kb + ln + 64 * j;
+                if (k >= p.n_bins) continue;
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    // complex64 rounding of the (centre-referenced) spectrum, then fp32 |.|^2 like the reference's numpy expression
+                    const float xr = (float)(re[j][f] * (double)p.spec_scale), xi = (float)(im[j][f] * (double)p.spec_scale);
+                    float v = xr * xr + xi * xi;
+                    if (p.power == 1) v = sqrtf(v);
+                    s_p[(4 * wv + f) * pstride + k] = v;
+                }
             }
         }
         __syncthreads();
@@ -158,7 +251,11 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
         const int nfeat = p.n_feat;
         const int total = nfr * nfeat;
         float local_max = -INFINITY;
+#ifdef MMFE_DFT_ABL_NOOUT
+        for (int i = threadIdx.x; i < (p.n_rows < 0 ? FR * nfeat : kThreads); i += kThreads) {
+#else
         for (int i = threadIdx.x; i < FR * nfeat; i += kThreads) {
+#endif
             int f, m;
             if (p.layout == MMFE_LAYOUT_FEAT_MAJOR) { m = i / FR; f = i - m * FR; }    // frames fastest: matches out[row][m][t]
             else { f = i / nfeat; m = i - f * nfeat; }                                  // features fastest: matches out[row][t][m]
@@ -242,11 +339,12 @@ int dftgen_prepare(Plan& plan) {
         set_error("dftgen: needs 2 <= n_fft <= 4096 and the window inside the DFT input");
         return MMFE_EINVAL;
     }
-    std::vector<double> tw(2 * (size_t)s.n_fft);
+    // half-step twiddles exp(-2 pi i n / 2N), n < 2N
+    std::vector<double> tw(4 * (size_t)s.n_fft);
     const double pi = 3.14159265358979323846;
-    for (int n = 0; n < s.n_fft; ++n) {
-        tw[2 * n] = std::cos(2.0 * pi * n / s.n_fft);
-        tw[2 * n + 1] = -std::sin(2.0 * pi * n / s.n_fft);
+    for (int n = 0; n < 2 * s.n_fft; ++n) {
+        tw[2 * n] = std::cos(pi * n / s.n_fft);
+        tw[2 * n + 1] = -std::sin(pi * n / s.n_fft);
     }
     int rc;
     if ((rc = upload(&plan.d_tw64, tw))) return rc;
@@ -310,7 +408,7 @@ int dftgen_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
         if (rc) return rc;
         a.rowmax = plan.d_rowmax;
     }
-    const size_t lds = (size_t)s.n_fft * 16 + (size_t)s.win_len * FR * 8 + (size_t)FR * (plan.n_bins + 1) * 4;
+    const size_t lds = (size_t)s.n_fft * 32 + (size_t)(s.win_len + 1) * FR * 8 + (size_t)FR * (plan.n_bins + 1) * 4;
     if (lds > 160 * 1024) {
         set_error("dftgen: n_fft %d / win_len %d need %zu bytes of LDS", s.n_fft, s.win_len, lds);
         return MMFE_EINVAL;

@@ -42,8 +42,9 @@ constexpr int kMaxHop = 160;
 constexpr int kMaxSpan = 7 * kMaxHop + kN;          // samples under one wave pass: 1520
 constexpr int kPF = (kMaxSpan / 4 + 63) / 64;       // prefetch registers (16-byte) per lane: 6
 constexpr int kTileStride = 18;                     // complex numbers per transpose-tile row (16 + padding, keeps rows 16-byte aligned)
-constexpr int kPairBytes = 25 * kTileStride * 8;    // 3600: transpose tile / natural-order spectrum of one frame pair
-constexpr int kWaveBytes = 4 * kPairBytes;          // 14400: one LDS work area per wave, reused by every phase
+constexpr int kPairBytes = 25 * kTileStride * 8 + 112;   // 3712: transpose tile / natural-order spectrum of one frame pair; = 32 dwords
+                                                         // mod 64, so the two pairs of a 32-lane half sit on disjoint LDS banks
+constexpr int kWaveBytes = 4 * kPairBytes;          // 14848: one LDS work area per wave, reused by every phase
 constexpr int kPS = 216;                            // floats between the power spectra of consecutive frames (= 24 mod 64: 8 frames on 8 bank groups)
 constexpr int kPGuard = 8;                          // floats in front of bin 0 (a bin run may start below 0)
 constexpr int kTwBytes = 25 * 16 * 8;               // W400^(b*c) table, [c][b]
