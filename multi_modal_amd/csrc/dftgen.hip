@@ -49,6 +49,7 @@ struct DftArgs {
     float log_of_floor;
     float out_shift, out_scale;
     int layout;
+    int p_alias;           // the power spectra reuse the LDS space of the staged taps
     const double* window;      // win_len doubles
     const double2* tw;         // n_fft entries exp(-2 pi i n / n_fft), float64
     const int32_t* band_start;
@@ -72,7 +73,9 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2* s_tw = reinterpret_cast<double2*>(smem);                     // 2*n_fft half-step twiddles
     double* s_u = reinterpret_cast<double*>(s_tw + 2 * p.n_fft);          // win_len * FR, [tap][frame], float64
-    float* s_p = reinterpret_cast<float*>(s_u + (p.win_len + 1) * FR);                                     // FR * (n_bins + 1), [frame][bin]
+    // power spectra [frame][bin]: they take over the tap array once the DFT loop is done with it when they fit
+    // (fewer bytes per block = one more resident block per CU), else they get their own space behind it
+    float* s_p = p.p_alias ? reinterpret_cast<float*>(s_u) : reinterpret_cast<float*>(s_u + (p.win_len + 1) * FR);                                     // FR * (n_bins + 1), [frame][bin]
     const int pstride = p.n_bins + 1;
 
     for (int i = threadIdx.x; i < 2 * p.n_fft; i += kThreads) s_tw[i] = p.tw[i];
@@ -116,11 +119,7 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
             if (interior) {
                 const float* fp = rp + base;
                 const bool pre = p.preemph != 0.f && !p.remove_dc;
-#ifdef MMFE_DFT_ABL_NOSTAGE
-                for (int j0 = threadIdx.x / FR; j0 < (p.n_rows < 0 ? p.win_len : 8 * kRows); j0 += 8 * kRows) {
-#else
                 for (int j0 = threadIdx.x / FR; j0 < p.win_len; j0 += 8 * kRows) {
-#endif
                     float x[8], xp[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
@@ -208,11 +207,7 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
 #pragma unroll
                 for (int f = 0; f < 4; ++f) { re[j][f] = 0.0; im[j][f] = 0.0; }
             }
-#ifdef MMFE_DFT_ABL_NOLOOP
-            for (int i = 0; i < (p.n_rows < 0 ? H : 1); ++i) {
-#else
             for (int i = 0; i < H; ++i) {
-#endif
                 // the centre tap of an odd window pairs with itself: its odd part is the row of zeros behind the taps
                 const double2* ep = reinterpret_cast<const double2*>(s_u + (hi0 + i) * FR + 4 * wv);
                 const double2* op = reinterpret_cast<const double2*>(s_u + ((odd && i == 0) ? L : lo0 - i) * FR + 4 * wv);
@@ -231,6 +226,7 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
                     }
                 }
             }
+            if (p.p_alias) __syncthreads();        // every wave is done reading the taps (one bin group only in this mode)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = kb + ln + 64 * j;
@@ -251,11 +247,7 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
         const int nfeat = p.n_feat;
         const int total = nfr * nfeat;
         float local_max = -INFINITY;
-#ifdef MMFE_DFT_ABL_NOOUT
-        for (int i = threadIdx.x; i < (p.n_rows < 0 ? FR * nfeat : kThreads); i += kThreads) {
-#else
         for (int i = threadIdx.x; i < FR * nfeat; i += kThreads) {
-#endif
             int f, m;
             if (p.layout == MMFE_LAYOUT_FEAT_MAJOR) { m = i / FR; f = i - m * FR; }    // frames fastest: matches out[row][m][t]
             else { f = i / nfeat; m = i - f * nfeat; }                                  // features fastest: matches out[row][t][m]
@@ -408,7 +400,9 @@ int dftgen_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
         if (rc) return rc;
         a.rowmax = plan.d_rowmax;
     }
-    const size_t lds = (size_t)s.n_fft * 32 + (size_t)(s.win_len + 1) * FR * 8 + (size_t)FR * (plan.n_bins + 1) * 4;
+    const size_t p_bytes = (size_t)FR * (plan.n_bins + 1) * 4;
+    a.p_alias = (plan.n_bins <= 256 && p_bytes <= (size_t)s.win_len * FR * 8) ? 1 : 0;
+    const size_t lds = (size_t)s.n_fft * 32 + (size_t)(s.win_len + 1) * FR * 8 + (a.p_alias ? 0 : p_bytes);
     if (lds > 160 * 1024) {
         set_error("dftgen: n_fft %d / win_len %d need %zu bytes of LDS", s.n_fft, s.win_len, lds);
         return MMFE_EINVAL;
@@ -423,7 +417,9 @@ int dftgen_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
     MMFE_HIP_CHECK(hipGetDevice(&dev));
     MMFE_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int64_t work = n_rows * ((frames_valid + FR - 1) / FR);
-    const int grid = (int)std::min<int64_t>(work, (int64_t)cus * 8);
+    int resident = 1;       // persistent blocks: as many as fit at once, so that every block gets the same share of the work
+    MMFE_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, reinterpret_cast<const void*>(&dftgen_kernel), kThreads, lds));
+    const int grid = (int)std::min<int64_t>(work, (int64_t)cus * std::max(1, resident));
     hipLaunchKernelGGL(dftgen_kernel, dim3(grid), dim3(kThreads), lds, stream, a);
     MMFE_HIP_CHECK(hipGetLastError());
     if (clamp) return clamp_affine_launch(plan, out, n_rows, out_frames * a.n_feat, stream);
