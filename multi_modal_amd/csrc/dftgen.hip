@@ -283,9 +283,13 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
     }
 }
 
-__global__ void rowmax_init_kernel(int* rowmax, int n) {
+// extremes[0..cap) = running maximum, extremes[cap..2cap) = running minimum, both in ordered-int form
+__global__ void rowmax_init_kernel(int* extremes, int n, int cap) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) rowmax[i] = float_to_ordered(-INFINITY);
+    if (i < n) {
+        extremes[i] = float_to_ordered(-INFINITY);
+        extremes[cap + i] = float_to_ordered(INFINITY);
+    }
 }
 
 // second pass of clamp_below_max: x = max(x, rowmax - c), then affine
@@ -307,7 +311,7 @@ int rowmax_init_launch(const Plan& plan, int64_t n_rows, hipStream_t stream) {
         return MMFE_EINVAL;
     }
     hipLaunchKernelGGL(rowmax_init_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream,
-                       reinterpret_cast<int*>(plan.d_rowmax), (int)n_rows);
+                       reinterpret_cast<int*>(plan.d_rowmax), (int)n_rows, (int)plan.rowmax_capacity);
     MMFE_HIP_CHECK(hipGetLastError());
     return MMFE_OK;
 }

@@ -233,7 +233,7 @@ int mmfe_plan_create(const mmfe_spec* spec, const void* window, const int32_t* b
             }
             if (rc == MMFE_OK && spec->clamp_below_max > 0.f) {
                 p->rowmax_capacity = 1 << 20;
-                if (hipMalloc((void**)&p->d_rowmax, (size_t)p->rowmax_capacity * sizeof(float)) != hipSuccess) {
+                if (hipMalloc((void**)&p->d_rowmax, 2 * (size_t)p->rowmax_capacity * sizeof(float)) != hipSuccess) {      // maxima, then minima
                     set_error("hipMalloc of the row-max scratch failed");
                     rc = MMFE_ENOMEM;
                 }

@@ -98,7 +98,7 @@ struct Plan {
     int32_t* d_band_len = nullptr;
     int32_t* d_band_off = nullptr;
     float* d_band_w = nullptr;
-    float* d_rowmax = nullptr;        // scratch for clamp_below_max (allocated lazily at plan creation for a max batch)
+    float* d_rowmax = nullptr;        // scratch for clamp_below_max: per-row maxima [0, capacity) and minima [capacity, 2*capacity)
     int64_t rowmax_capacity = 0;
     int impl = 0;                     // which kernel family serves this plan
 };
@@ -118,7 +118,7 @@ int dftgen_prepare(Plan& plan);
 int dftgen_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames_natural,
                   int64_t out_frames, float* out, hipStream_t stream);
 
-// per-row maximum + clamp pass of clamp_below_max: out = (max(out, rowmax - c) + out_shift) * out_scale
+// per-row extremes + clamp pass of clamp_below_max: out = (max(out, rowmax - c) + out_shift) * out_scale
 int rowmax_init_launch(const Plan& plan, int64_t n_rows, hipStream_t stream);
 int clamp_affine_launch(const Plan& plan, float* out, int64_t n_rows, int64_t per_row, hipStream_t stream);
 

@@ -55,7 +55,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct Rfft400Args {
     RowSource src;
     float* out;
-    int* rowmax;               // per-row running maximum of the log values (ordered-int form), or nullptr
+    int* rowmax;               // per-row running maximum of the stored values (ordered-int form), or nullptr
+    int* rowmin;               // per-row running minimum, likewise
     int n_rows;
     int n_samples;
     int frames_valid;          // frames computed per row
@@ -302,7 +303,7 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
         wave_lds_fence();
 
         // ---- banded mel on the matrix pipe, log, affine, store ---------------------------------------
-        float lmax = -INFINITY;
+        float lmax = -INFINITY, lmin = INFINITY;
 #pragma unroll
         for (int st = 0; st < kStreams; ++st) {
             if (kSteps[st] == 0) continue;
@@ -323,7 +324,10 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
             for (int i = 0; i < 4; ++i) v[i] = apply_log_affine(acc[i], p.la, none_flag);
             if (d >= 0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) lmax = tf + i < p.frames_valid ? fmaxf(lmax, v[i]) : lmax;
+                for (int i = 0; i < 4; ++i) {
+                    lmax = tf + i < p.frames_valid ? fmaxf(lmax, v[i]) : lmax;
+                    lmin = tf + i < p.frames_valid ? fminf(lmin, v[i]) : lmin;
+                }
                 if (p.layout == MMFE_LAYOUT_FEAT_MAJOR) {
                     float* o = p.out + ((int64_t)cur_row * p.n_mel + m) * p.out_frames + tf;
                     if (p.vec_store && tf + 4 <= p.frames_valid) {
@@ -342,10 +346,37 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
             }
         }
         if (p.rowmax != nullptr) {
-            for (int off = 32; off > 0; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
-            if (lane == 0 && lmax > -INFINITY) atomicMax(p.rowmax + cur_row, float_to_ordered(lmax));
+            for (int off = 32; off > 0; off >>= 1) {
+                lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+                lmin = fminf(lmin, __shfl_xor(lmin, off));
+            }
+            if (lane == 0 && lmax > -INFINITY) {
+                atomicMax(p.rowmax + cur_row, float_to_ordered(lmax));
+                atomicMin(p.rowmin + cur_row, float_to_ordered(lmin));
+            }
         }
         wave_lds_fence();
+    }
+}
+
+// clamp_below_max on the finished features.  The affine map (x + shift) * scale with scale > 0 is monotone, so it
+// commutes with the clamp: out = max(out, rowmax_out - c * scale).  Rows whose minimum already clears the threshold
+// (any signal with less than c decades of dynamic range) are skipped, so the pass normally reads two ints per row.
+__global__ void __launch_bounds__(256) clamp_rows_kernel(float* out, const int* rowmax, const int* rowmin, int64_t per_row,
+                                                         int n_rows, int chunks_per_row, float delta) {
+    const int64_t n_work = (int64_t)n_rows * chunks_per_row;
+    for (int64_t wk = blockIdx.x; wk < n_work; wk += gridDim.x) {
+        const int row = (int)(wk / chunks_per_row);
+        const int chunk = (int)(wk - (int64_t)row * chunks_per_row);
+        const int omx = rowmax[row], omn = rowmin[row];
+        const float mx = __int_as_float(omx >= 0 ? omx : omx ^ 0x7fffffff);
+        const float mn = __int_as_float(omn >= 0 ? omn : omn ^ 0x7fffffff);
+        const float thr = mx - delta;
+        if (!(mn < thr)) continue;
+        const int64_t len = (per_row + chunks_per_row - 1) / chunks_per_row;
+        const int64_t lo = (int64_t)chunk * len, hi = lo + len < per_row ? lo + len : per_row;
+        float* o = out + (int64_t)row * per_row;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) o[i] = fmaxf(o[i], thr);
     }
 }
 
@@ -387,7 +418,7 @@ bool rfft400_supports(const mmfe_spec& s) {
         if (std::string(f) == "1") return false;
     }
     return s.n_fft == kN && s.n_mel > 0 && s.n_mel <= 128 && s.power == 2 && s.spec_scale == 1.0f && !s.window_f64 &&
-           !s.remove_dc && s.preemph == 0.f && s.hop >= 1 && s.hop <= kMaxHop &&
+           !s.remove_dc && s.preemph == 0.f && s.hop >= 1 && s.hop <= kMaxHop && !(s.clamp_below_max > 0.f && !(s.out_scale > 0.f)) &&
            (s.frames_mode == MMFE_FRAMES_CENTER || s.frames_mode == MMFE_FRAMES_SNIP);
 }
 
@@ -514,7 +545,7 @@ int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64
     a.n_mel = s.n_mel;
     a.layout = s.layout;
     a.vec_store = (out_frames % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 1 : 0;
-    a.la = make_log_affine(s, clamp);      // with the clamp, shift and scale follow in the second pass
+    a.la = make_log_affine(s);
     a.window = plan.d_window;
     a.tw = reinterpret_cast<const float2*>(plan.d_tw_a);
     a.mel_poff = plan.d_mel4_kstart;
@@ -524,6 +555,7 @@ int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64
         int rc = rowmax_init_launch(plan, n_rows, stream);
         if (rc) return rc;
         a.rowmax = reinterpret_cast<int*>(plan.d_rowmax);
+        a.rowmin = a.rowmax + plan.rowmax_capacity;
     }
     const bool vec = s.hop % 4 == 0 && a.shift % 4 == 0 && src.offsets == nullptr && src.stride % 4 == 0 && reinterpret_cast<uintptr_t>(src.base) % 16 == 0;
     int rc = MMFE_EINVAL;
@@ -543,7 +575,17 @@ int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64
 #undef MMFE_R400_SHAPE
     if (!found) { set_error("rfft400: plan has no kernel variant"); return MMFE_EINVAL; }
     if (rc) return rc;
-    if (clamp) rc = clamp_affine_launch(plan, out, n_rows, out_frames * (int64_t)s.n_mel, stream);
+    if (clamp) {
+        int dev = 0, cus = 256;
+        MMFE_HIP_CHECK(hipGetDevice(&dev));
+        MMFE_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const int64_t per_row = out_frames * (int64_t)s.n_mel;
+        const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(64, per_row / 4096));
+        const int grid = (int)std::min<int64_t>(n_rows * chunks, (int64_t)cus * 8);
+        hipLaunchKernelGGL(clamp_rows_kernel, dim3(grid), dim3(256), 0, stream, out, a.rowmax, a.rowmin, per_row, (int)n_rows, chunks,
+                           s.clamp_below_max * s.out_scale);
+        MMFE_HIP_CHECK(hipGetLastError());
+    }
     return rc;
 }
 

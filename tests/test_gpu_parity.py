@@ -322,6 +322,23 @@ def test_long_utterance_logmel(mm, O, precision):
     assert mx <= 1e-4
 
 
+def test_logmel_clamp_active(mm, O):
+    """Utterances whose dynamic range exceeds 8 decades, so the (max - 8) clamp really changes cells: an impulse,
+    half silence / half noise, pure silence (every cell at the floor) and a DC offset."""
+    n = 32000
+    half = synth("noise0.1", n, 41)
+    half[: n // 2] = 0.0
+    x = np.stack([synth("impulse", n, 40), half, synth("silence", n, 42), synth("dc", n, 43)])
+    ref = np.stack([O.whisper_logmel(c) for c in x])
+    for precision in ("float32", "float64"):
+        got = mm.logmel.log_mel_spectrogram(torch.from_numpy(x).cuda(), precision=precision).cpu().numpy()
+        floor_cells = int((ref[1] == ref[1].min()).sum())
+        assert floor_cells > 1000                      # the clamp is active in the half-silent clip
+        mx, p999 = _stats(got - ref)
+        print("clamp", precision, "max", mx, "p99.9", p999)
+        assert mx <= 1e-4
+
+
 @pytest.mark.parametrize("n", [160, 161, 399, 400, 401, 1279, 1280, 1281, 4000, 16000, 48001])
 def test_logmel_lengths(mm, O, n):
     """Ragged utterance lengths: partial last octets, rows shorter than one window (reflection wraps more than once)."""
