@@ -61,6 +61,9 @@ constexpr int kPGuard = 8;                   // floats in front of the power spe
 #ifndef MMFE_PREFETCH_AT
 #define MMFE_PREFETCH_AT 1   // 0: after the first-half transpose write, 1: after the second-half spectrum write
 #endif
+#ifndef MMFE_PREFETCH_EARLY
+#define MMFE_PREFETCH_EARLY 6
+#endif
 #ifndef MMFE_TWIDDLE_REGS
 #define MMFE_TWIDDLE_REGS 1   // 1: first-half twiddles live in 30 VGPRs instead of LDS
 #endif
@@ -110,11 +113,11 @@ struct FbankArgs {
 // slice that sits in the zero padding read `safe` and select zero.  EXACT promises
 // 32*(NA-1) < win_len <= 32*NA, so only the last slice needs the per-lane test and all other loads
 // are one base register plus an immediate offset.  The VEC2 form needs an even win_len.
-template <int NA, bool VEC2, bool EXACT>
+template <int NA, bool VEC2, bool EXACT, int A0 = 0, int A1 = NA>
 __device__ __forceinline__ void load_frame(float2 (&v)[NA], const float* fp, const float* safe, bool valid, int b, int win_len) {
     const float* base = (valid ? fp : safe) + 2 * b;
 #pragma unroll
-    for (int a = 0; a < NA; ++a) {
+    for (int a = A0; a < A1; ++a) {
         const int idx = 32 * a + 2 * b;
         const bool whole = EXACT && a < NA - 1;        // compile-time: slice entirely inside the window
         if (VEC2) {
@@ -285,6 +288,15 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
         // prefetch the next quad of this wave here, where register pressure is lowest (the first-half
         // registers are dead); the loads stay in flight under the second half of this iteration
         MMFE_STAMP(2);
+#if MMFE_PREFETCH_AT == 2
+        // split prefetch: the first MMFE_PREFETCH_EARLY slices of the next quad are requested here, ahead of the
+        // second half (as many as the register budget leaves room for), the rest after it
+        advance(row, q);
+        const int nt_e = (int)q * 4 + fl;
+        const bool nvalid_e = row < (unsigned)p.n_rows && nt_e < p.frames_valid;
+        const float* nfp_e = row_ptr(p.src, row < (unsigned)p.n_rows ? row : 0) + (int64_t)nt_e * p.hop;
+        load_frame<NA, VEC2, EXACT, 0, (MMFE_PREFETCH_EARLY < NA ? MMFE_PREFETCH_EARLY : NA)>(nxt, nfp_e, safe, nvalid_e, b, p.win_len);
+#endif
 #if MMFE_PREFETCH_AT == 0
         advance(row, q);
         {
@@ -314,6 +326,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
         wave_lds_fence();
 
         // ---- real-FFT recombination on pairs (k, 256-k), power spectrum ------------------------
+#if MMFE_PREFETCH_AT == 2
+        load_frame<NA, VEC2, EXACT, (MMFE_PREFETCH_EARLY < NA ? MMFE_PREFETCH_EARLY : NA), NA>(nxt, nfp_e, safe, nvalid_e, b, p.win_len);
+#endif
 #if MMFE_PREFETCH_AT == 1
         advance(row, q);
         {
@@ -703,7 +718,12 @@ int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
     const int blocks_per_cu = std::max<int>(1, (int)((160 * 1024) / lds));
     const int64_t want = (quads + kWavesPerBlock - 1) / kWavesPerBlock;
     const int by_waves = std::max(1, (4 * MMFE_FBANK_MIN_WAVES_PER_SIMD) / kWavesPerBlock);
-    const int grid = (int)std::min<int64_t>(want, (int64_t)cus * std::min(blocks_per_cu, by_waves));
+    int per_cu = std::min(blocks_per_cu, by_waves);
+    if (const char* e = std::getenv("MMFE_FBANK_BLOCKS_PER_CU")) {     // tuning: fewer resident blocks (the grid is persistent)
+        const int v = std::atoi(e);
+        if (v >= 1 && v < per_cu) per_cu = v;
+    }
+    const int grid = (int)std::min<int64_t>(want, (int64_t)cus * per_cu);
 
     // 8-byte lane loads need every frame start to be 8-byte aligned
     bool vec2 = (s.hop % 2 == 0) && (s.win_len % 2 == 0) && (reinterpret_cast<uintptr_t>(src.base) % 8 == 0);
