@@ -393,12 +393,13 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
             // lane holds filter (64*set + lane) of the quad's 4 frames in registers 0..3.  Frames past
             // the row's last frame repeat frame 0's store (same address, same value): no branch.
             MMFE_STAMP(6);
+            float vab[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { vab[r] = accA[r]; vab[4 + r] = NGB > 0 ? accB[r] : 1.f; }
+            apply_log_affine_block(vab, p.la);
             float va[4], vb[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                va[r] = apply_log_affine(accA[r], p.la, none_flag);
-                vb[r] = NGB > 0 ? apply_log_affine(accB[r], p.la, none_flag) : 0.f;
-            }
+            for (int r = 0; r < 4; ++r) { va[r] = vab[r]; vb[r] = vab[4 + r]; }
             const int n_ok = p.frames_valid - t0;         // >= 1, wave-uniform
             float* obase = p.out + ((int64_t)cur_row * p.out_rows + t0) * p.n_mel + lane;
 #ifdef MMFE_ABL_NOSTORE

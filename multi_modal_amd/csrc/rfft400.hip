@@ -173,9 +173,6 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
         pa[st] = parea + (kSteps[st] > 0 ? p.mel_poff[st * 64 + lane] : 0);
         dst[st] = kSteps[st] > 0 ? p.mel_dst[st * 64 + lane] : -1;
     }
-    float none_flag = p.la.none_flag;
-    asm volatile("" : "+v"(none_flag));         // a per-lane value from here on: selects on it stay v_cndmask
-
     // ---- work distribution: octet = 8 consecutive frames of one row; a block takes kWaves consecutive
     //      octets per round, so its waves stream one contiguous region and fill whole output lines ------
     const unsigned opr = (unsigned)(p.frames_valid + 7) >> 3;      // octets per row
@@ -303,45 +300,54 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
         wave_lds_fence();
 
         // ---- banded mel on the matrix pipe, log, affine, store ---------------------------------------
+        float v[4 * kStreams];
+#pragma unroll
+        for (int st = 0; st < kStreams; ++st) {
+            f32x4 acc = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (kSteps[st] > 0) {
+                acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < kSteps[st]; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(pa[st][s], wreg[kStepOff[st] + s], acc, 0, 0, 0);
+                if (SPLIT && st == kLastStream) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] += __shfl_xor(acc[i], 32);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[4 * st + i] = acc[i];
+        }
+        apply_log_affine_block(v, p.la);
         float lmax = -INFINITY, lmin = INFINITY;
 #pragma unroll
         for (int st = 0; st < kStreams; ++st) {
             if (kSteps[st] == 0) continue;
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < kSteps[st]; ++s)
-                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(pa[st][s], wreg[kStepOff[st] + s], acc, 0, 0, 0);
-            if (SPLIT && st == kLastStream) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] += __shfl_xor(acc[i], 32);
-            }
-            // lane = 4*blk + j holds filter j of the block's unit for its 4 frames in registers 0..3
+            // lane = 4*blk + j holds filter j of the block's unit for its 4 frames in v[4*st .. 4*st+3]
             const int d = dst[st];
             const int m = d & 0xffff;
             const int tf = t0 + 4 * (d >> 16);          // first of the lane's 4 frames
-            float v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = apply_log_affine(acc[i], p.la, none_flag);
             if (d >= 0) {
+                if (p.rowmax != nullptr) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    lmax = tf + i < p.frames_valid ? fmaxf(lmax, v[i]) : lmax;
-                    lmin = tf + i < p.frames_valid ? fminf(lmin, v[i]) : lmin;
+                    for (int i = 0; i < 4; ++i) {
+                        lmax = tf + i < p.frames_valid ? fmaxf(lmax, v[4 * st + i]) : lmax;
+                        lmin = tf + i < p.frames_valid ? fminf(lmin, v[4 * st + i]) : lmin;
+                    }
                 }
                 if (p.layout == MMFE_LAYOUT_FEAT_MAJOR) {
                     float* o = p.out + ((int64_t)cur_row * p.n_mel + m) * p.out_frames + tf;
                     if (p.vec_store && tf + 4 <= p.frames_valid) {
-                        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(o) = make_float4(v[4 * st], v[4 * st + 1], v[4 * st + 2], v[4 * st + 3]);
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            if (tf + i < p.frames_valid) o[i] = v[i];
+                            if (tf + i < p.frames_valid) o[i] = v[4 * st + i];
                     }
                 } else {
                     float* o = p.out + ((int64_t)cur_row * p.out_frames + tf) * p.n_mel + m;
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        if (tf + i < p.frames_valid) o[(int64_t)i * p.n_mel] = v[i];
+                        if (tf + i < p.frames_valid) o[(int64_t)i * p.n_mel] = v[4 * st + i];
                 }
             }
         }
