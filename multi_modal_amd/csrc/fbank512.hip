@@ -407,12 +407,22 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
 #else
             if (lane < p.n_mel) {
 #endif
+                if (n_ok >= 4) {        // whole quad inside the row (wave-uniform): plain strided stores
 #pragma unroll
-                for (int r = 0; r < 4; ++r) MMFE_OUT_STORE(r < n_ok ? va[r] : va[0], obase + (r < n_ok ? r * p.n_mel : 0));
+                    for (int r = 0; r < 4; ++r) MMFE_OUT_STORE(va[r], obase + r * p.n_mel);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) MMFE_OUT_STORE(r < n_ok ? va[r] : va[0], obase + (r < n_ok ? r * p.n_mel : 0));
+                }
             }
             if (NGB > 0 && 64 + lane < p.n_mel) {
+                if (n_ok >= 4) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) MMFE_OUT_STORE(r < n_ok ? vb[r] : vb[0], obase + 64 + (r < n_ok ? r * p.n_mel : 0));
+                    for (int r = 0; r < 4; ++r) MMFE_OUT_STORE(vb[r], obase + 64 + r * p.n_mel);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) MMFE_OUT_STORE(r < n_ok ? vb[r] : vb[0], obase + 64 + (r < n_ok ? r * p.n_mel : 0));
+                }
             }
         } else {
             const int t = t0 + fl;
