@@ -83,6 +83,35 @@ __device__ __forceinline__ float row16_sum(float s) {
     return s;
 }
 
+__device__ __forceinline__ float read_lane(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// Maximum / minimum over each 16-lane row, then over the wave's four rows (lanes 0, 16, 32, 48 read back as
+// scalars): every lane ends with the wave-wide extreme, no LDS traffic.
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_mov<DPP_QUAD_XOR1>(v));
+    v = fmaxf(v, dpp_mov<DPP_QUAD_XOR2>(v));
+    v = fmaxf(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_mov<DPP_ROW_MIRROR>(v));
+    const float r0 = read_lane(v, 0), r1 = read_lane(v, 16), r2 = read_lane(v, 32), r3 = read_lane(v, 48);
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+__device__ __forceinline__ float wave_min(float v) {
+    v = fminf(v, dpp_mov<DPP_QUAD_XOR1>(v));
+    v = fminf(v, dpp_mov<DPP_QUAD_XOR2>(v));
+    v = fminf(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+    v = fminf(v, dpp_mov<DPP_ROW_MIRROR>(v));
+    const float r0 = read_lane(v, 0), r1 = read_lane(v, 16), r2 = read_lane(v, 32), r3 = read_lane(v, 48);
+    return fminf(fminf(r0, r1), fminf(r2, r3));
+}
+
+// Value of lane (l + 32) for lanes l < 32 (v_permlane32_swap, a VALU operation); lanes 32..63 get their own value back.
+__device__ __forceinline__ float upper_half_value(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[1]);
+}
+
 // Orders LDS traffic between the lanes of one wave (no instruction is emitted for it beyond what
 // the memory model requires: a wave's DS operations already execute in program order).
 __device__ __forceinline__ void wave_lds_fence() {

@@ -28,8 +28,10 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <vector>
 
 namespace mmfe {
 
@@ -73,7 +75,23 @@ struct Rfft400Args {
     const int32_t* mel_poff;   // [kStreams][64]: float offset of the lane's bin run in the wave's spectrum area
     const int32_t* mel_dst;    // [kStreams][64]: filter | frame group << 16, or -1 for an idle lane
     const float* mel_w;        // [total steps][64], step-major
+    unsigned long long* stamps;  // diagnostic build only
 };
+
+// Diagnostic build only (-DMMFE_STAMPS): per-phase s_memtime shares of the main loop, printed by the launcher.
+#ifdef MMFE_STAMPS
+#define MMFE_STAMP(i)                                                                                   \
+    do {                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        unsigned long long _t;                                                                          \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                      \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        if ((i) > 0) st_acc[(i) - 1] += _t - st_prev;                                                   \
+        st_prev = _t;                                                                                   \
+    } while (0)
+#else
+#define MMFE_STAMP(i) do { } while (0)
+#endif
 
 // 5-point forward DFT in place.
 __device__ __forceinline__ void dft5(float2& x0, float2& x1, float2& x2, float2& x3, float2& x4) {
@@ -218,7 +236,11 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
     float* const pw_a = parea + (2 * pr) * kPS + kPGuard;
     float* const pw_b = pw_a + kPS;
 
+#ifdef MMFE_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
+#endif
     while (row < (unsigned)p.n_rows) {
+        MMFE_STAMP(0);
         const int t0 = (int)oq * 8;          // first frame of the octet
         const unsigned cur_row = row;
 
@@ -239,19 +261,38 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
         }
         wave_lds_fence();
 
+        MMFE_STAMP(1);
         // ---- next octet's samples: in flight under the rest of this pass ----------------------------
         advance(row, oq);
         fetch(row, oq);
 
         // ---- 400-point complex FFT, first half: 25-point FFT over a, twiddle, transpose ------------
         fft25(z);
+        // The twiddle table and the tile are both LDS, and the compiler cannot tell them apart: a twiddle read
+        // placed after a tile write stays behind it and then costs a full LDS round trip before its product can be
+        // written.  So the reads run one group of 8 ahead of the writes: three round trips instead of 24.
+        {
+            float2 tw_cur[8], tw_nxt[8];
 #pragma unroll
-        for (int c = 0; c < 25; ++c) {
-            float2 v = z[fft25_pos(c)];
-            if (c > 0) v = cmul(v, s_tw[c * 16 + b]);
-            tile[c * kTileStride + b] = v;
+            for (int j = 0; j < 8; ++j) tw_cur[j] = s_tw[(1 + j) * 16 + b];
+            tile[b] = z[fft25_pos(0)];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                if (g < 2) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) tw_nxt[j] = s_tw[(9 + 8 * g + j) * 16 + b];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = 1 + 8 * g + j;
+                    tile[c * kTileStride + b] = cmul(z[fft25_pos(c)], tw_cur[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tw_cur[j] = tw_nxt[j];
+            }
         }
         wave_lds_fence();
+        MMFE_STAMP(2);
         float2 u0[16], u1[16];
         {
             const float2* r0 = tile + b * kTileStride;
@@ -261,6 +302,7 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
         }
         wave_lds_fence();
 
+        MMFE_STAMP(3);
         // ---- second half: 16-point FFTs of columns b and b+16; Z[c + 25 d] parked in natural order ----
         fft16(u0);
         fft16(u1);
@@ -272,6 +314,7 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
         }
         wave_lds_fence();
 
+        MMFE_STAMP(4);
         // ---- separate the two real spectra, power ------------------------------------------------
         float p_a[13], p_b[13];
 #pragma unroll
@@ -299,6 +342,7 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
         }
         wave_lds_fence();
 
+        MMFE_STAMP(5);
         // ---- banded mel on the matrix pipe, log, affine, store ---------------------------------------
         float v[4 * kStreams];
 #pragma unroll
@@ -311,12 +355,13 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
                     acc = __builtin_amdgcn_mfma_f32_4x4x1f32(pa[st][s], wreg[kStepOff[st] + s], acc, 0, 0, 0);
                 if (SPLIT && st == kLastStream) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i] += __shfl_xor(acc[i], 32);
+                    for (int i = 0; i < 4; ++i) acc[i] += upper_half_value(acc[i]);      // blocks 8..15 hold the second halves of the runs
                 }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[4 * st + i] = acc[i];
         }
+        MMFE_STAMP(6);
         apply_log_affine_block(v, p.la);
         float lmax = -INFINITY, lmin = INFINITY;
 #pragma unroll
@@ -352,17 +397,23 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
             }
         }
         if (p.rowmax != nullptr) {
-            for (int off = 32; off > 0; off >>= 1) {
-                lmax = fmaxf(lmax, __shfl_xor(lmax, off));
-                lmin = fminf(lmin, __shfl_xor(lmin, off));
-            }
+            lmax = wave_max(lmax);
+            lmin = wave_min(lmin);
             if (lane == 0 && lmax > -INFINITY) {
                 atomicMax(p.rowmax + cur_row, float_to_ordered(lmax));
                 atomicMin(p.rowmin + cur_row, float_to_ordered(lmin));
             }
         }
+        MMFE_STAMP(7);
+#ifdef MMFE_STAMPS
+        st_acc[7] += 1;
+#endif
         wave_lds_fence();
     }
+#ifdef MMFE_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) p.stamps[((size_t)blockIdx.x * kWaves + wave) * 8 + i] = st_acc[i];
+#endif
 }
 
 // clamp_below_max on the finished features.  The affine map (x + shift) * scale with scale > 0 is monotone, so it
@@ -410,11 +461,37 @@ int launch_variant(const Rfft400Args& a, int64_t octets, hipStream_t stream) {
     MMFE_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     int blocks_per_cu = 1;
     MMFE_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, 64 * kWaves, lds));
+    if (const char* e = std::getenv("MMFE_R400_BLOCKS_PER_CU")) {     // tuning: fewer resident blocks (the grid is persistent)
+        const int v = std::atoi(e);
+        if (v >= 1 && v < blocks_per_cu) blocks_per_cu = v;
+    }
     const int64_t want = (octets + kWaves - 1) / kWaves;
     const int grid = (int)std::min<int64_t>(want, (int64_t)cus * std::max(1, blocks_per_cu));
+#ifdef MMFE_STAMPS
+    Rfft400Args ta = a;
+    const size_t n_st = (size_t)grid * kWaves * 8;
+    MMFE_HIP_CHECK(hipMalloc((void**)&ta.stamps, n_st * 8));
+    MMFE_HIP_CHECK(hipMemset(ta.stamps, 0, n_st * 8));
+    hipLaunchKernelGGL((rfft400_kernel<HOP, VEC, S0, S1, S2, S3, SPLIT>), dim3(grid), dim3(64 * kWaves), lds, stream, ta);
+    MMFE_HIP_CHECK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(n_st);
+    MMFE_HIP_CHECK(hipMemcpy(h.data(), ta.stamps, n_st * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(ta.stamps);
+    static int printed = 0;
+    if (printed++ < 2) {
+        double sum[8] = {0};
+        for (size_t w = 0; w < n_st / 8; ++w) for (int i = 0; i < 8; ++i) sum[i] += (double)h[w * 8 + i];
+        const char* names[7] = {"stage+gather", "prefetch+fft25+Twrite", "Tread", "fft16x2+Zwrite", "separate+Pwrite", "mel(mfma)", "log+store+extremes"};
+        double tot = 0; for (int i = 0; i < 7; ++i) tot += sum[i];
+        for (int i = 0; i < 7; ++i) fprintf(stderr, "[stamps] %-22s %8.1f ticks/iter  %5.1f%%\n", names[i], sum[i] / sum[7], 100.0 * sum[i] / tot);
+        fprintf(stderr, "[stamps] total %.1f ticks/iter, %.0f iterations\n", tot / sum[7], sum[7]);
+    }
+    return MMFE_OK;
+#else
     hipLaunchKernelGGL((rfft400_kernel<HOP, VEC, S0, S1, S2, S3, SPLIT>), dim3(grid), dim3(64 * kWaves), lds, stream, a);
     MMFE_HIP_CHECK(hipGetLastError());
     return MMFE_OK;
+#endif
 }
 
 }  // namespace
