@@ -3,6 +3,8 @@
 configs[4] per GPU) on one GPU: units/s, achieved algorithmic GB/s and fraction of the 8 TB/s HBM peak.
 
     python scripts/bench_configs.py [har] [epic] [logmel] [--iters 20]
+
+bench.py imports `run_config` to append the same lines to its JSON under "secondary".
 """
 import json
 import os
@@ -28,37 +30,44 @@ def timeit(fn, iters, warmup=3):
     return sum(ms) / len(ms), ms[0]
 
 
-def main():
-    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["har", "epic", "logmel"]
-    iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 20
-    dev = torch.device("cuda", 0)
+def _line(config, unit, n, per, avg, mn):
+    rate = n / (avg * 1e-3)
+    return {"config": config, "value": round(rate, 1), "unit": unit, "ms": round(avg, 4), "min_ms": round(mn, 4),
+            "algorithmic_bytes_per_unit": per, "GB/s": round(per * rate / 1e9, 1), "frac_of_8TBs": round(per * rate / 8e12, 4)}
+
+
+def run_config(name: str, dev: torch.device, iters: int = 20) -> dict:
     g = torch.Generator(device=dev).manual_seed(4321)
-    if "har" in which:
+    if name == "har":
         B = 262144
         x = torch.randn(B, 6, 192, device=dev, generator=g)
         out = torch.empty(B, 6, 17, 49, device=dev)
         avg, mn = timeit(lambda: mm.stft_mag(x, out=out), iters)
-        per = 6 * 192 * 4 + 6 * 17 * 49 * 4
-        print(json.dumps({"config": "HAR (262144, 6, 192) -> (262144, 6, 17, 49)", "windows_per_s": B / (avg * 1e-3), "ms": avg, "min_ms": mn,
-                          "bytes_per_window": per, "GB/s": per * B / (avg * 1e-3) / 1e9, "frac_of_8TBs": per * B / (avg * 1e-3) / 8e12}))
-        del x, out
-    if "epic" in which:
+        return _line("HAR (262144, 6, 192) -> (262144, 6, 17, 49), kernel stft32", "windows/s", B, 6 * 192 * 4 + 6 * 17 * 49 * 4, avg, mn)
+    if name == "epic":
         B = 4096
         x = (0.1 * torch.randn(B, 30672, device=dev, generator=g)).clamp_(-1, 1)
         out = torch.empty(B, 256, 256, device=dev)
         avg, mn = timeit(lambda: mm.log_specgram_batch(x, div255=True, out=out), iters)
-        per = 30672 * 4 + 256 * 256 * 4
-        print(json.dumps({"config": "EPIC (4096, 30672) -> (4096, 256, 256), n_fft 511", "clips_per_s": B / (avg * 1e-3), "ms": avg, "min_ms": mn,
-                          "bytes_per_clip": per, "GB/s": per * B / (avg * 1e-3) / 1e9, "frac_of_8TBs": per * B / (avg * 1e-3) / 8e12}))
-        del x, out
-    if "logmel" in which:
+        return _line("EPIC (4096, 30672) -> (4096, 256, 256), n_fft 511, kernel dftgen (compute-bound)", "clips/s", B,
+                     30672 * 4 + 256 * 256 * 4, avg, mn)
+    if name == "logmel":
         B = 1024
         x = (0.1 * torch.randn(B, 480000, device=dev, generator=g)).clamp_(-1, 1)
         out = torch.empty(B, 80, 3000, device=dev)
         avg, mn = timeit(lambda: mm.logmel.log_mel_spectrogram(x, out=out), iters)
-        per = 480000 * 4 + 80 * 3000 * 4
-        print(json.dumps({"config": "long-utterance log-mel (1024, 480000) -> (1024, 80, 3000), n_fft 400, kernel " + mm.plans.last_kernel(), "utt_per_s": B / (avg * 1e-3), "ms": avg,
-                          "min_ms": mn, "bytes_per_utt": per, "GB/s": per * B / (avg * 1e-3) / 1e9, "frac_of_8TBs": per * B / (avg * 1e-3) / 8e12}))
+        return _line("long-utterance log-mel (1024, 480000) -> (1024, 80, 3000), n_fft 400, kernel " + mm.plans.last_kernel(),
+                     "utterances/s", B, 480000 * 4 + 80 * 3000 * 4, avg, mn)
+    raise ValueError(name)
+
+
+def main():
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["har", "epic", "logmel"]
+    iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 20
+    dev = torch.device("cuda", 0)
+    for name in which:
+        print(json.dumps(run_config(name, dev, iters)), flush=True)
+        torch.cuda.empty_cache()
 
 
 if __name__ == "__main__":

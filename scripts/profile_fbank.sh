@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary"
 run() { # name, rocprof args...
     local name=$1; shift
     timeout -s KILL 240 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- $BENCH > "$OUT/$name.log" 2>&1
