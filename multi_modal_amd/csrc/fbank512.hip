@@ -52,10 +52,13 @@ constexpr int kPGuard = 8;                   // floats in front of the power spe
 #ifndef MMFE_FBANK_NT
 #define MMFE_FBANK_NT 1
 #endif
+typedef float mmfe_f32x4 __attribute__((ext_vector_type(4)));
 #if MMFE_FBANK_NT
 #define MMFE_OUT_STORE(v, ptr) __builtin_nontemporal_store((v), (ptr))
+#define MMFE_OUT_STORE4(a, b, c, d, ptr) __builtin_nontemporal_store(mmfe_f32x4{(a), (b), (c), (d)}, reinterpret_cast<mmfe_f32x4*>(ptr))
 #else
 #define MMFE_OUT_STORE(v, ptr) (*(ptr) = (v))
+#define MMFE_OUT_STORE4(a, b, c, d, ptr) (*reinterpret_cast<mmfe_f32x4*>(ptr) = mmfe_f32x4{(a), (b), (c), (d)})
 #endif
 
 #ifndef MMFE_PREFETCH_AT
@@ -88,6 +91,7 @@ struct FbankArgs {
     int hop;
     int win_len;
     int n_mel;
+    int vec_out;               // n_mel % 4 == 0 and a 16-byte aligned output tensor: 16-byte stores
     float preemph;
     float mean_scale;          // 1/win_len when the per-frame mean is removed, else 0
     LogAffine la;
@@ -185,8 +189,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
     // same-index 4-byte accesses of different frame slots on different banks
     float* pbuf = reinterpret_cast<float*>(fbuf) + kPGuard + 8 * fl;
 
-    // matrix-pipe mel: lane = 4*blk + q supplies A = P[frame slot q][run(blk) + s] and B = weight of
-    // filter (64*set + lane) at that bin; weights stay in registers for the life of the kernel
+    // matrix-pipe mel: lane = 4*blk + q supplies the weight of filter (64*set + lane) at bin run(blk) + s (operand A,
+    // row q of the block) and P[frame slot q][run(blk) + s] (operand B, column q); weights stay in registers for
+    // the life of the kernel
     float wreg[kMfmaMel ? kStepsA + kStepsB : 1];
     const float* pa_A = nullptr;
     const float* pa_B = nullptr;
@@ -381,47 +386,41 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
             for (int i = 0; i < kAccB; ++i) pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < kStepsA; ++s)
-                pa[s % kAccA] = __builtin_amdgcn_mfma_f32_4x4x1f32(pa_A[s], wreg[s], pa[s % kAccA], 0, 0, 0);
+                pa[s % kAccA] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[s], pa_A[s], pa[s % kAccA], 0, 0, 0);
 #pragma unroll
             for (int s = 0; s < kStepsB; ++s)
-                pb[s % kAccB] = __builtin_amdgcn_mfma_f32_4x4x1f32(pa_B[s], wreg[kStepsA + s], pb[s % kAccB], 0, 0, 0);
+                pb[s % kAccB] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[kStepsA + s], pa_B[s], pb[s % kAccB], 0, 0, 0);
             f32x4 accA = pa[0], accB = pb[0];
 #pragma unroll
             for (int i = 1; i < kAccA; ++i) accA += pa[i];
 #pragma unroll
             for (int i = 1; i < kAccB; ++i) accB += pb[i];
-            // lane holds filter (64*set + lane) of the quad's 4 frames in registers 0..3.  Frames past
-            // the row's last frame repeat frame 0's store (same address, same value): no branch.
+            // Operand A carries the weights (row i = filter 4*blk + i, taken from lane 4*blk + i) and operand B the
+            // spectrum (column q = frame slot q, from lane 4*blk + q), so lane 4*blk + q ends up with 4 CONSECUTIVE
+            // filters of ONE frame in registers 0..3: one 16-byte store per filter set, and the 16 lanes that share
+            // a frame write 256 contiguous bytes of its row.
             MMFE_STAMP(6);
             float vab[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { vab[r] = accA[r]; vab[4 + r] = NGB > 0 ? accB[r] : 1.f; }
             apply_log_affine_block(vab, p.la);
-            float va[4], vb[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { va[r] = vab[r]; vb[r] = vab[4 + r]; }
             const int n_ok = p.frames_valid - t0;         // >= 1, wave-uniform
-            float* obase = p.out + ((int64_t)cur_row * p.out_rows + t0) * p.n_mel + lane;
+            const int q4 = lane & 3, f0 = lane & ~3;      // frame slot, first filter of the lane's block
+            float* orow = p.out + ((int64_t)cur_row * p.out_rows + t0 + q4) * p.n_mel + f0;
 #ifdef MMFE_ABL_NOSTORE
-            if (lane < p.n_mel && va[0] == 123.456f && vb[1] == 654.321f) {
+            if (q4 < n_ok && vab[0] == 123.456f && vab[5] == 654.321f) {
 #else
-            if (lane < p.n_mel) {
+            if (q4 < n_ok) {
 #endif
-                if (n_ok >= 4) {        // whole quad inside the row (wave-uniform): plain strided stores
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) MMFE_OUT_STORE(va[r], obase + r * p.n_mel);
+                if (p.vec_out) {        // n_mel % 4 == 0 and an aligned tensor: blocks are whole
+                    if (f0 < p.n_mel) MMFE_OUT_STORE4(vab[0], vab[1], vab[2], vab[3], orow);
+                    if (NGB > 0 && 64 + f0 < p.n_mel) MMFE_OUT_STORE4(vab[4], vab[5], vab[6], vab[7], orow + 64);
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) MMFE_OUT_STORE(r < n_ok ? va[r] : va[0], obase + (r < n_ok ? r * p.n_mel : 0));
-                }
-            }
-            if (NGB > 0 && 64 + lane < p.n_mel) {
-                if (n_ok >= 4) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) MMFE_OUT_STORE(vb[r], obase + 64 + r * p.n_mel);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) MMFE_OUT_STORE(r < n_ok ? vb[r] : vb[0], obase + 64 + (r < n_ok ? r * p.n_mel : 0));
+                    for (int i = 0; i < 4; ++i) {
+                        if (f0 + i < p.n_mel) orow[i] = vab[i];
+                        if (NGB > 0 && 64 + f0 + i < p.n_mel) orow[64 + i] = vab[4 + i];
+                    }
                 }
             }
         } else {
@@ -701,6 +700,7 @@ int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
     a.hop = s.hop;
     a.win_len = s.win_len;
     a.n_mel = s.n_mel;
+    a.vec_out = (s.n_mel % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 1 : 0;
     a.preemph = s.preemph;
     a.mean_scale = s.remove_dc ? 1.0f / (float)s.win_len : 0.0f;
     a.la = make_log_affine(s);
