@@ -446,3 +446,32 @@ def test_full_size_properties(mm):
     b = mm.fbank_batch(base[:2] * 2.0, sample_frequency=16000, window_type="hanning", num_mel_bins=128, frame_shift=25)
     mask = a > -15.0
     assert torch.allclose((b - a)[mask], torch.full_like(a[mask], float(np.log(4.0))), atol=2e-5)
+
+
+def test_full_size_properties_har(mm):
+    """BASELINE configuration 3 at full size (262 144 windows x 6 axes): equal windows give bit-identical spectrograms
+    wherever they sit in the batch; scaling the input by a power of two scales the magnitudes exactly."""
+    g = torch.Generator(device="cuda").manual_seed(4321)
+    base = torch.randn(64, 6, 192, device="cuda", generator=g)
+    small = mm.stft_mag(base)
+    big = mm.stft_mag(base.repeat(4096, 1, 1))
+    assert big.shape == (262144, 6, 17, 49)
+    assert torch.equal(big.view(4096, 64, 6, 17, 49), small.unsqueeze(0).expand(4096, -1, -1, -1, -1))
+    assert torch.equal(mm.stft_mag(base * 4.0), small * 4.0)
+    assert torch.isfinite(big).all()
+
+
+def test_full_size_properties_logmel(mm):
+    """BASELINE configuration 5 per GPU (1024 utterances of 30 s): position independence of the radix kernel, and
+    the clamp invariant of every utterance (no cell below max - 2 after the (x + 4) / 4 map)."""
+    g = torch.Generator(device="cuda").manual_seed(99)
+    base = (0.1 * torch.randn(8, 480000, device="cuda", generator=g)).clamp_(-1, 1)
+    small = mm.logmel.log_mel_spectrogram(base)
+    big = mm.logmel.log_mel_spectrogram(base.repeat(128, 1))
+    assert big.shape == (1024, 80, 3000)
+    assert torch.equal(big.view(128, 8, 80, 3000), small.unsqueeze(0).expand(128, -1, -1, -1))
+    mx = big.amax(dim=(1, 2))
+    mn = big.amin(dim=(1, 2))
+    assert torch.all(mn >= mx - 2.0 - 1e-6)
+    assert torch.isfinite(big).all()
+
