@@ -32,6 +32,10 @@
  *     tensor.data_ptr()).  The library allocates only plan-lifetime constant tables.
  *   - mmfe_run* is asynchronous on the given HIP stream (NULL = the default stream); it never
  *     synchronises and never allocates.
+ *   - Plans are immutable after creation and may be shared between threads and streams, with one
+ *     exception: a plan with clamp_below_max > 0 owns a per-row scratch (row maxima and minima), so
+ *     two mmfe_run* calls on such a plan must not overlap on the device (issue them on one stream, or
+ *     create one plan per stream); a call handles at most 2^20 rows.
  *   - There is no CPU path: creating a plan without a usable gfx950 device fails.
  */
 #ifndef MMFE_H
@@ -82,7 +86,7 @@ extern "C" {
 typedef struct mmfe_spec {
     int32_t struct_size;   /* = sizeof(mmfe_spec) */
     int32_t kind;          /* MMFE_KIND_* */
-    int32_t n_fft;         /* DFT length (any value >= 2 for LOGSPEC; power of two for FBANK / STFT_MAG) */
+    int32_t n_fft;         /* DFT length: any value in [2, 4096]; 512 and 400 have radix kernels, STFT_MAG needs 32 */
     int32_t win_len;       /* number of window taps (<= n_fft); FRAME: frame_length */
     int32_t win_off;       /* position of tap 0 inside the n_fft-long DFT input (zeros elsewhere) */
     int32_t hop;
