@@ -366,6 +366,20 @@ def test_logmel_hops_and_alignment(mm, O, hop, off):
     assert mx <= 1e-4
 
 
+@pytest.mark.parametrize("n_mels,kernel", [(40, "rfft400"), (64, "rfft400"), (80, "rfft400"), (128, "rfft400"), (23, "dftgen")])
+def test_logmel_filter_bank_sizes(mm, O, n_mels, kernel):
+    """Every instantiated mel stream shape of the radix kernel (2, 3 and 4 streams, with and without a split last
+    stream), and a bank that fits none of them and therefore takes the any-length kernel."""
+    x = np.stack([synth("noise0.1", 16000, 60 + n_mels), synth("sine+noise", 16000, 61 + n_mels)])
+    ref = np.stack([O.whisper_logmel(c, n_mels=n_mels) for c in x])
+    got = mm.logmel.log_mel_spectrogram(torch.from_numpy(x).cuda(), n_mels=n_mels).cpu().numpy()
+    assert mm.plans.last_kernel() == kernel
+    assert got.shape == ref.shape == (2, n_mels, 100)
+    mx, _ = _stats(got - ref)
+    print("n_mels", n_mels, kernel, "max", mx)
+    assert mx <= 1e-4
+
+
 def test_logmel_kernels_agree(mm):
     """The radix kernel and the any-length float64 kernel serve the same plan parameters: same shapes, same values
     to float32 FFT accuracy, on a batch large enough to wrap the persistent grid several times."""
