@@ -411,19 +411,11 @@ int dftgen_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
         set_error("dftgen: n_fft %d / win_len %d need %zu bytes of LDS", s.n_fft, s.win_len, lds);
         return MMFE_EINVAL;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        MMFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dftgen_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
-    int dev = 0, cus = 256;
-    MMFE_HIP_CHECK(hipGetDevice(&dev));
-    MMFE_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    int resident = 1, cus = 256;      // persistent blocks: as many as fit at once, so that every block gets the same share of the work
+    int rc = kernel_prepare(reinterpret_cast<const void*>(&dftgen_kernel), kThreads, lds, &resident, &cus);
+    if (rc) return rc;
     const int64_t work = n_rows * ((frames_valid + FR - 1) / FR);
-    int resident = 1;       // persistent blocks: as many as fit at once, so that every block gets the same share of the work
-    MMFE_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, reinterpret_cast<const void*>(&dftgen_kernel), kThreads, lds));
-    const int grid = (int)std::min<int64_t>(work, (int64_t)cus * std::max(1, resident));
+    const int grid = (int)std::min<int64_t>(work, (int64_t)cus * resident);
     hipLaunchKernelGGL(dftgen_kernel, dim3(grid), dim3(kThreads), lds, stream, a);
     MMFE_HIP_CHECK(hipGetLastError());
     if (clamp) return clamp_affine_launch(plan, out, n_rows, out_frames * a.n_feat, stream);

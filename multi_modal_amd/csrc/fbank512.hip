@@ -452,15 +452,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
 
 template <int NA, bool VEC2, bool EXACT, int NGA, int NGB>
 int launch_variant(const FbankArgs& args, int grid, size_t lds, hipStream_t stream) {
-    // raising the dynamic-LDS limit is idempotent; it is repeated per device on first use
-    static unsigned long long done_mask = 0;
-    int dev = 0;
-    MMFE_HIP_CHECK(hipGetDevice(&dev));
-    if (!(done_mask >> (dev & 63) & 1ull)) {
-        MMFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fbank512_kernel<NA, VEC2, EXACT, NGA, NGB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        done_mask |= 1ull << (dev & 63);
-    }
+    int resident = 0, cus = 0;      // raises the variant's dynamic-LDS limit on this device (once); the grid is sized by the caller
+    const int prc = kernel_prepare(reinterpret_cast<const void*>(&fbank512_kernel<NA, VEC2, EXACT, NGA, NGB>), 64 * kWavesPerBlock, lds,
+                                   &resident, &cus);
+    if (prc) return prc;
 #ifdef MMFE_STAMPS
     FbankArgs targs = args;
     const size_t n_st = (size_t)grid * kWavesPerBlock * 8;

@@ -1,12 +1,48 @@
 // C ABI of libmmfe.so: plan management, shape rules, dispatch to the kernel families.
 #include "mmfe_internal.h"
 
+#include <map>
+#include <mutex>
+#include <set>
+#include <tuple>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <new>
 
 namespace mmfe {
+
+int kernel_prepare(const void* fn, int threads, size_t lds, int* blocks_per_cu, int* cus) {
+    struct Key {
+        const void* fn; int dev; int threads; size_t lds;
+        bool operator<(const Key& o) const { return std::tie(fn, dev, threads, lds) < std::tie(o.fn, o.dev, o.threads, o.lds); }
+    };
+    struct Val { int blocks; int cus; };
+    static std::mutex mu;
+    static std::map<Key, Val> cache;
+    static std::set<std::pair<const void*, int>> raised;
+    int dev = 0;
+    MMFE_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    const Key key{fn, dev, threads, lds};
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        if (!raised.count({fn, dev})) {
+            MMFE_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised.insert({fn, dev});
+        }
+        Val v{1, 256};
+        MMFE_HIP_CHECK(hipDeviceGetAttribute(&v.cus, hipDeviceAttributeMultiprocessorCount, dev));
+        MMFE_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v.blocks, fn, threads, lds));
+        if (v.blocks < 1) v.blocks = 1;
+        it = cache.emplace(key, v).first;
+    }
+    *blocks_per_cu = it->second.blocks;
+    *cus = it->second.cus;
+    return MMFE_OK;
+}
+
 
 static thread_local std::string g_last_error;
 

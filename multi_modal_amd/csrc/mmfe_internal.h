@@ -135,6 +135,11 @@ int fill_pad_rows(float* out, int64_t n_rows, int64_t out_frames, int64_t first_
 
 int feature_sums_launch(const float* x, int64_t n, double* sums, hipStream_t stream);
 
+// Launch-geometry helpers (thread-safe, cached per kernel and device).
+//   kernel_prepare: raises the kernel's dynamic-LDS limit to the CU's 160 KB on the current device (once) and
+//   returns how many blocks of `threads` threads with `lds` bytes of dynamic LDS are resident per CU, and the CU count.
+int kernel_prepare(const void* fn, int threads, size_t lds, int* blocks_per_cu, int* cus);
+
 template <typename T>
 int upload(T** dptr, const std::vector<T>& host) {
     *dptr = nullptr;

@@ -451,16 +451,9 @@ template <int HOP, bool VEC, int S0, int S1, int S2, int S3, bool SPLIT>
 int launch_variant(const Rfft400Args& a, int64_t octets, hipStream_t stream) {
     const void* fn = reinterpret_cast<const void*>(&rfft400_kernel<HOP, VEC, S0, S1, S2, S3, SPLIT>);
     const size_t lds = kTwBytes + (size_t)kWaves * kWaveBytes;
-    static unsigned long long done_mask = 0;
-    int dev = 0, cus = 256;
-    MMFE_HIP_CHECK(hipGetDevice(&dev));
-    if (!(done_mask >> (dev & 63) & 1ull)) {
-        MMFE_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        done_mask |= 1ull << (dev & 63);
-    }
-    MMFE_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    int blocks_per_cu = 1;
-    MMFE_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, 64 * kWaves, lds));
+    int blocks_per_cu = 1, cus = 256;
+    int rc = kernel_prepare(fn, 64 * kWaves, lds, &blocks_per_cu, &cus);
+    if (rc) return rc;
     if (const char* e = std::getenv("MMFE_R400_BLOCKS_PER_CU")) {     // tuning: fewer resident blocks (the grid is persistent)
         const int v = std::atoi(e);
         if (v >= 1 && v < blocks_per_cu) blocks_per_cu = v;

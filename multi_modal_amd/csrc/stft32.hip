@@ -262,21 +262,14 @@ int stft32_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
                 reinterpret_cast<uintptr_t>(src.base) % 16 == 0) ? 1 : 0;
     a.vec_out = (((int64_t)best_r * 17 * n_frames) % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 1 : 0;
     const size_t lds = (size_t)best_r * per_row_bytes;
-    int dev = 0, cus = 256;
-    MMFE_HIP_CHECK(hipGetDevice(&dev));
-    MMFE_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int64_t groups = (n_rows + best_r - 1) / best_r;
     const bool aligned_hop = s.hop % 4 == 0;
-    static unsigned long long done_mask[2] = {0, 0};
     const void* fn = aligned_hop ? reinterpret_cast<const void*>(&stft32_kernel<true>) : reinterpret_cast<const void*>(&stft32_kernel<false>);
-    if (!(done_mask[aligned_hop] >> (dev & 63) & 1ull)) {
-        MMFE_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        done_mask[aligned_hop] |= 1ull << (dev & 63);
-    }
     // persistent blocks: exactly as many as are resident at once (registers, LDS and wave slots all count)
-    int blocks_per_cu = 1;
-    MMFE_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, best_threads, lds));
-    const int grid = (int)std::min<int64_t>(groups, (int64_t)cus * std::max(1, blocks_per_cu));
+    int blocks_per_cu = 1, cus = 256;
+    const int rc = kernel_prepare(fn, best_threads, lds, &blocks_per_cu, &cus);
+    if (rc) return rc;
+    const int grid = (int)std::min<int64_t>(groups, (int64_t)cus * blocks_per_cu);
     if (aligned_hop) hipLaunchKernelGGL(stft32_kernel<true>, dim3(grid), dim3(best_threads), lds, stream, a);
     else hipLaunchKernelGGL(stft32_kernel<false>, dim3(grid), dim3(best_threads), lds, stream, a);
     MMFE_HIP_CHECK(hipGetLastError());
