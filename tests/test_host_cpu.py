@@ -150,6 +150,43 @@ def test_wrapper_argument_errors_need_no_gpu():
     for args in [(0, 0, 60.0, 240000), (10 ** 6, 0, 60.0, 240000), (120, 30, 60.0, 240000), (77, 3, 50.0, 100000)]:
         assert epic.sound_slice_bounds(*args) == O.sound_slice_bounds(*args)
     assert torch.equal(mm.spec_to_tensor(np.full((4, 5), 255.0, np.float32)), torch.ones(1, 4, 5))
+    with pytest.raises(ValueError):
+        mm.logmel.log_mel_spectrogram(torch.zeros(1, 16000), precision="float16")
+    assert isinstance(mm.plans.last_kernel(), str)
+
+
+def test_mel_stream_shapes_cover_the_common_banks():
+    """The n_fft = 400 radix kernel has template instances for a fixed list of mel stream shapes
+    (csrc/rfft400.hip: kShapes).  Recompute the shape of the common banks the way the library does and
+    check that each fits an instance; a bank that fits none silently takes the slower any-length kernel."""
+    from multi_modal_amd import melbank
+    shapes = [((5, 19, 17, 0), True), ((8, 20, 20, 0), True), ((4, 8, 12, 24), False), ((12, 44, 0, 0), False), ((36, 32, 0, 0), True)]
+
+    def stream_shape(fb):
+        bs, bl, _ = melbank.dense_to_bands(np.asarray(fb, dtype=np.float32))
+        n_mel = len(bs)
+        nfb = (n_mel + 3) // 4
+        units = 2 * nfb
+        ns = (units + 15) // 16
+        run = []
+        for f in range(nfb):
+            ms = [m for m in range(4 * f, min(4 * f + 4, n_mel)) if bl[m] > 0]
+            run.append(max(bs[m] + bl[m] for m in ms) - min(bs[m] for m in ms) if ms else 0)
+        split = units - 16 * (ns - 1) <= 8
+        steps = [0, 0, 0, 0]
+        for u in range(units):
+            st, f = u // 16, u >> 1
+            need = (run[f] + 1) // 2 if (split and st == ns - 1) else run[f]
+            steps[st] = max(steps[st], need, 1)
+        return tuple(int(v) for v in steps), split
+
+    def fits(steps, split):
+        return any(sp == split and all((a > 0) == (b > 0) and a >= b for a, b in zip(sh, steps)) for sh, sp in shapes)
+
+    for n_mels in (40, 64, 80, 128):
+        assert fits(*stream_shape(melbank.slaney_mel_filters(201, n_mels, 16000))), n_mels
+    for n_mels in (40, 64, 80, 128):
+        assert fits(*stream_shape(melbank.kaldi_mel_banks(n_mels, 400, 16000.0).numpy())), n_mels
 
 
 def test_shard_ranges():
