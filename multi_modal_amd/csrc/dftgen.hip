@@ -102,7 +102,8 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
         const int nfr = min(FR, p.frames_valid - t0);
         const float* rp = row_ptr(p.src, row);
 
-        __syncthreads();   // previous work item is done with s_u / s_p (and s_tw is loaded)
+        // barriers order LDS only: the previous item's output stores stay in flight instead of being waited for
+        lds_barrier();   // previous work item is done with s_u / s_p (and s_tw is loaded)
         // ---- stage windowed frames: u[j][f].  16 consecutive threads take one tap of the 16 frames, so a wave
         //      writes 4 whole rows of the [tap][frame] array (512 contiguous bytes, no LDS bank conflict); its
         //      global reads are 16 runs of 4 consecutive samples, which the overlapping frames keep in L1/L2 ----
@@ -155,7 +156,7 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (p.remove_dc) {
             // kaldi order: subtract the frame mean, pre-emphasise the centred samples, then window.
             // One thread per frame walks its taps (rarely used path: only for window sizes the radix
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
                     prev = g;
                 }
             }
-            __syncthreads();
+            lds_barrier();
         }
 
         // ---- fold the windowed taps about the window centre: e at the upper tap's slot, o at the lower one's -----
@@ -183,7 +184,7 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
             s_u[(hi0 + q) * FR + f] = b + a;
             s_u[(lo0 - q) * FR + f] = b - a;
         }
-        __syncthreads();
+        lds_barrier();
 
         // ---- direct DFT about the window centre.  Register blocking: wave w owns frames 4w..4w+3, lane l owns
         //      bins l, l+64, l+128, l+192 (of each group of 256 bins): 32 float64 accumulators per thread, and per
@@ -226,7 +227,7 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
                     }
                 }
             }
-            if (p.p_alias) __syncthreads();        // every wave is done reading the taps (one bin group only in this mode)
+            if (p.p_alias) lds_barrier();        // every wave is done reading the taps (one bin group only in this mode)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = kb + ln + 64 * j;
@@ -241,7 +242,7 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
 
         // ---- mel (optional), log, affine, store ------------------------------------------------
         const int nfeat = p.n_feat;

@@ -122,4 +122,12 @@ __device__ __forceinline__ void wave_lds_fence() {
 #endif
 }
 
+// Block barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter,
+// i.e. it would wait for the drain phase's global stores to reach memory at every phase change.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 }  // namespace mmfe

@@ -47,14 +47,6 @@ __device__ __forceinline__ float2 tw32(int k) {
     return make_float2(-S[k], -S[8 - k]);
 }
 
-// Block barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter,
-// i.e. it would wait for the drain phase's global stores to reach memory at every phase change.
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
 constexpr int kPrefetch = 4;     // float4 registers per thread for the next group's samples
 
 // One group = R consecutive rows, three phases:
