@@ -111,8 +111,9 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
             const int f = threadIdx.x & (FR - 1);
             const int base = (t0 + f) * p.hop + p.centre_shift;
             constexpr int kRows = kThreads / FR;       // taps staged per sweep of the block
+            constexpr int kSweep = 16;                 // loads per thread in flight
             // Blocks whose 16 frames lie inside the row (all but the first and last few of a row) read without
-            // any padding test, 8 taps per thread in flight at once; a sweep that waits for one load at a
+            // any padding test, 16 taps per thread in flight at once (one memory round trip for windows up to 256 taps); a sweep that waits for one load at a
             // time would leave the block idle for a memory round trip per 16 taps.
             const int lo_s = t0 * p.hop + p.centre_shift - 1;                                  // incl. the pre-emphasis neighbour
             const int hi_s = (t0 + FR - 1) * p.hop + p.centre_shift + p.win_len;
@@ -120,17 +121,17 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
             if (interior) {
                 const float* fp = rp + base;
                 const bool pre = p.preemph != 0.f && !p.remove_dc;
-                for (int j0 = threadIdx.x / FR; j0 < p.win_len; j0 += 8 * kRows) {
-                    float x[8], xp[8];
+                for (int j0 = threadIdx.x / FR; j0 < p.win_len; j0 += kSweep * kRows) {
+                    float x[kSweep], xp[kSweep];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < kSweep; ++u) {
                         const int j = j0 + u * kRows;
                         const int jc = j < p.win_len ? j : 0;
                         x[u] = fp[jc];
                         xp[u] = pre ? fp[jc > 0 ? jc - 1 : 0] : 0.f;
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < kSweep; ++u) {
                         const int j = j0 + u * kRows;
                         if (j < p.win_len) {
                             const float xv = pre ? x[u] - p.preemph * xp[u] : x[u];
