@@ -237,3 +237,16 @@ def test_partition_all_gather_world2_gloo(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert "ok" in o
+
+
+def test_bench_cpu_baseline_fields():
+    """The CPU leg of bench.py (the oracle timed per clip) on a tiny budget: the fields the JSON line carries."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.BYTES_PER_CLIP == 811008
+    r = bench.cpu_baseline(budget_s=0.2, max_clips=3)
+    assert r["unit"] == "clips/s" and r["cores"] == 1 and r["kind"] == "port" and r["value"] > 0 and "clips" in r["sample"]
+
