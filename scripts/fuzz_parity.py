@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep: the HIP path against the CPU oracle over random parameter sets and lengths.
+
+    python scripts/fuzz_parity.py [--cases 200] [--seed 0]
+
+Not part of the test suite (it takes a minute or two); it is the wide net behind the fixed cases of
+tests/test_gpu_parity.py.  Every case prints one line; the script exits non-zero on the first case outside its
+tolerance.  Tolerances are those of the fixed tests: kaldi log-mel p99.9 <= 1e-4 and max <= 2e-3, log-mel
+(n_fft 400) max <= 1e-4, HAR magnitudes max <= 1e-6, frame_signal exact.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import multi_modal_amd as mm  # noqa: E402
+from conftest import synth  # noqa: E402
+from oracle import frontend_oracle as O  # noqa: E402
+
+
+def stats(d):
+    d = np.abs(np.asarray(d, dtype=np.float64)).ravel()
+    return (0.0, 0.0) if d.size == 0 else (float(d.max()), float(np.percentile(d, 99.9)))
+
+
+def case_fbank(rng):
+    kind = rng.choice(["noise0.1", "uniform", "quiet"])
+    n = int(rng.integers(300, 60000))
+    kw = dict(num_mel_bins=int(rng.choice([23, 40, 64, 80, 128])),
+              frame_length=float(rng.choice([20.0, 25.0, 32.0])), frame_shift=float(rng.choice([5.0, 7.5, 10.0, 25.0])),
+              window_type=str(rng.choice(["hanning", "povey", "hamming", "rectangular", "blackman"])),
+              remove_dc_offset=bool(rng.integers(2)), preemphasis_coefficient=float(rng.choice([0.0, 0.97])),
+              round_to_power_of_two=bool(rng.integers(2)))
+    x = synth(kind, n, int(rng.integers(1 << 30)))
+    ref = O.kaldi_fbank(torch.from_numpy(x)[None], sample_frequency=16000, **kw).numpy()
+    got = mm.fbank(torch.from_numpy(x)[None].cuda(), sample_frequency=16000, **kw).cpu().numpy()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    mx, p = stats(got - ref)
+    return f"fbank[{mm.plans.last_kernel() if ref.size else '-'}] n={n} {kind} {kw}", mx, p, (p <= 1e-4 and mx <= 2e-3)
+
+
+def case_logmel(rng):
+    kind = rng.choice(["noise0.1", "uniform", "sine+noise", "quiet"])
+    n = int(rng.integers(200, 80000))
+    hop = int(rng.choice([160, 160, 160, 80, 100, 128, 150, 37]))
+    n_mels = int(rng.choice([40, 64, 80, 80, 128]))
+    off = int(rng.integers(0, 4))
+    base = synth(kind, n + 4, int(rng.integers(1 << 30)))
+    x = base[off:off + n]
+    ref = O.whisper_logmel(x, hop=hop, n_mels=n_mels)
+    got = mm.logmel.log_mel_spectrogram(torch.from_numpy(base).cuda()[None, off:off + n], hop_length=hop, n_mels=n_mels).cpu().numpy()[0]
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    mx, p = stats(got - ref)
+    return f"logmel[{mm.plans.last_kernel() if ref.size else '-'}] n={n} hop={hop} mels={n_mels} off={off} {kind}", mx, p, mx <= 1e-4
+
+
+def case_har(rng):
+    t = int(rng.integers(32, 700))
+    nov = int(rng.choice([28, 28, 24, 16, 0, 31, 30]))
+    shape = (int(rng.integers(1, 40)), int(rng.integers(1, 7)), t)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = O.stft_mag(x, nperseg=32, noverlap=nov)
+    got = mm.stft_mag(x, nperseg=32, noverlap=nov)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    mx, p = stats(got - ref)
+    return f"har {shape} noverlap={nov}", mx, p, mx <= 1e-6
+
+
+def case_frame(rng):
+    n = int(rng.integers(1, 5000))
+    fl = int(rng.integers(1, 600))
+    hop = int(rng.integers(1, 400))
+    x = torch.from_numpy(rng.standard_normal((int(rng.integers(1, 5)), n)).astype(np.float32))
+    w = torch.from_numpy(rng.standard_normal(fl).astype(np.float32)) if rng.integers(2) else None
+    ref = O.frame_signal(x, fl, hop, w)
+    got = mm.frame_signal(x.cuda(), fl, hop, None if w is None else w.cuda()).cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    mx = float((got - ref).abs().max()) if ref.numel() else 0.0
+    return f"frame n={n} frame_length={fl} hop={hop} window={'yes' if w is not None else 'no'}", mx, mx, mx == 0.0
+
+
+def main():
+    cases = int(sys.argv[sys.argv.index("--cases") + 1]) if "--cases" in sys.argv else 200
+    seed = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 0
+    rng = np.random.default_rng(seed)
+    makers = [case_fbank, case_fbank, case_logmel, case_logmel, case_har, case_frame]
+    worst = {}
+    for i in range(cases):
+        fn = makers[i % len(makers)]
+        name, mx, p, ok = fn(rng)
+        print(f"{i:4d} {'ok  ' if ok else 'FAIL'} max {mx:.3e} p99.9 {p:.3e}  {name}", flush=True)
+        fam = name.split(" ")[0]
+        worst[fam] = max(worst.get(fam, 0.0), mx)
+        if not ok:
+            sys.exit(1)
+    print("worst max|d| per family:", {k: f"{v:.3e}" for k, v in sorted(worst.items())})
+
+
+if __name__ == "__main__":
+    main()
