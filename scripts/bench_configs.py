@@ -62,8 +62,8 @@ def run_config(name: str, dev: torch.device, iters: int = 20) -> dict:
 
 
 def main():
-    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["har", "epic", "logmel"]
     iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 20
+    which = [a for a in sys.argv[1:] if a in ("har", "epic", "logmel")] or ["har", "epic", "logmel"]
     dev = torch.device("cuda", 0)
     for name in which:
         print(json.dumps(run_config(name, dev, iters)), flush=True)
