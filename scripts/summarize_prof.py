@@ -25,7 +25,16 @@ def main():
         out_json = sys.argv[sys.argv.index("--json") + 1]
         args = [a for a in args if a != out_json]
     summary = {"kernel": needle}
-    for f in glob.glob(os.path.join(root, "stats", "*", "*_kernel_stats.csv")):
+    def newest(pattern):
+        """One file per pass directory: the most recent one (a directory reused by several runs keeps the old CSVs)."""
+        by_dir = {}
+        for f in glob.glob(pattern):
+            d = os.path.dirname(f)
+            if d not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[d]):
+                by_dir[d] = f
+        return sorted(by_dir.values())
+
+    for f in newest(os.path.join(root, "stats", "*", "*_kernel_stats.csv")):
         for row in csv.DictReader(open(f)):
             if needle in row["Name"]:
                 summary["calls"] = int(row["Calls"])
@@ -35,7 +44,7 @@ def main():
                 summary["kernel_name"] = row["Name"]
     counters = defaultdict(list)
     meta = {}
-    for f in glob.glob(os.path.join(root, "pmc_*", "*", "*_counter_collection.csv")):
+    for f in newest(os.path.join(root, "pmc_*", "*", "*_counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             if needle in row["Kernel_Name"]:
                 counters[row["Counter_Name"]].append(float(row["Counter_Value"]))
