@@ -16,6 +16,7 @@
 // mel projection (from LDS), the log and the affine map and stores in the requested layout.
 #include "mmfe_internal.h"
 #include "fft_regs.h"
+#include "log_affine.h"
 
 #include <algorithm>
 #include <cmath>
@@ -44,10 +45,7 @@ struct DftArgs {
     float preemph;
     int power;
     float spec_scale;
-    int log_kind;
-    float log_floor;
-    float log_of_floor;
-    float out_shift, out_scale;
+    LogAffine la;          // log + affine stage (plain log when a clamp pass follows)
     int layout;
     int p_alias;           // the power spectra reuse the LDS space of the staged taps
     const double* window;      // win_len doubles
@@ -57,17 +55,6 @@ struct DftArgs {
     const int32_t* band_off;
     const float* band_w;
 };
-
-// `log_of_floor` is log(floor) rounded on the host, so floored cells carry the same value the
-// reference's CPU libm produces (device logf is within 1 ulp, not correctly rounded).
-__device__ __forceinline__ float dft_log(float x, int kind, float floor_, float log_of_floor) {
-    switch (kind) {
-        case MMFE_LOG_LN_MAX: return x <= floor_ ? log_of_floor : logf(x);
-        case MMFE_LOG_LN_ADD: return logf(x + floor_);
-        case MMFE_LOG_LOG10_MAX: return x <= floor_ ? log_of_floor : log10f(x);
-        default: return x;
-    }
-}
 
 __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -264,16 +251,14 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
             } else {
                 v = s_p[f * pstride + m];
             }
-            v = dft_log(v, p.log_kind, p.log_floor, p.log_of_floor);
+            float vv[1] = {v};
+            apply_log_affine_block(vv, p.la);      // hardware log2 + one fma; floored cells take the host-rounded log(floor)
+            v = vv[0];
             int64_t o;
             if (p.layout == MMFE_LAYOUT_FEAT_MAJOR) o = ((int64_t)row * nfeat + m) * p.out_frames + (t0 + f);
             else o = ((int64_t)row * p.out_frames + (t0 + f)) * nfeat + m;
-            if (p.rowmax != nullptr) {
-                p.out[o] = v;                 // clamp + affine happen in the second pass
-                local_max = fmaxf(local_max, v);
-            } else {
-                p.out[o] = (v + p.out_shift) * p.out_scale;
-            }
+            p.out[o] = v;
+            if (p.rowmax != nullptr) local_max = fmaxf(local_max, v);      // clamp + affine happen in the second pass
         }
         (void)total;
         if (p.rowmax != nullptr) {
@@ -392,9 +377,7 @@ int dftgen_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
     a.pad_mode = s.pad_mode;
     a.n_bins = plan.n_bins; a.n_mel = s.n_mel; a.n_feat = s.n_mel > 0 ? s.n_mel : plan.n_bins;
     a.remove_dc = s.remove_dc; a.preemph = s.preemph; a.power = s.power; a.spec_scale = s.spec_scale;
-    a.log_kind = s.log_kind; a.log_floor = s.log_floor;
-    a.log_of_floor = s.log_kind == MMFE_LOG_LOG10_MAX ? (float)std::log10((double)s.log_floor) : (float)std::log((double)s.log_floor);
-    a.out_shift = s.out_shift; a.out_scale = s.out_scale;
+    a.la = make_log_affine(s, s.clamp_below_max > 0.f);
     a.layout = s.layout;
     a.window = plan.d_window64;
     a.tw = reinterpret_cast<const double2*>(plan.d_tw64);
