@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--batch", type=int, default=4096, help="clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-allgather", action="store_true", help="multi-GPU: skip the separately timed all-gather of features")
     ap.add_argument("--no-secondary", action="store_true", help="skip the HAR / long-utterance / EPIC configurations")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--precondition", type=float, default=0.5, help="seconds of untimed launches before the warm-up steps")
@@ -131,25 +132,28 @@ def main():
 
     # ---- optional: all-gather of features (multi-GPU only), timed separately -------------------------
     gather = None
-    if use_dist:
-        full = torch.empty(world * B, OUT_FRAMES, N_MEL, device=dev)
-        for _ in range(2):
-            dist.all_gather_into_tensor(full, out)
-        fence()
-        k = max(3, min(args.steps, 10))
-        t0 = time.perf_counter()
-        for _ in range(k):
-            step()
-            dist.all_gather_into_tensor(full, out)
-        fence()
-        el = time.perf_counter() - t0
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-        recv = (world - 1) * out.numel() * 4
-        gather = {"clips_per_s_with_allgather": round(world * B * k / el, 1), "ms_per_step": round(1e3 * el / k, 3),
-                  "received_bytes_per_rank": recv, "steps": k}
-        del full
+    if use_dist and not args.no_allgather:
+        try:
+            full = torch.empty(world * B, OUT_FRAMES, N_MEL, device=dev)
+            for _ in range(2):
+                dist.all_gather_into_tensor(full, out)
+            fence()
+            k = max(3, min(args.steps, 10))
+            t0 = time.perf_counter()
+            for _ in range(k):
+                step()
+                dist.all_gather_into_tensor(full, out)
+            fence()
+            el = time.perf_counter() - t0
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+            recv = (world - 1) * out.numel() * 4
+            gather = {"clips_per_s_with_allgather": round(world * B * k / el, 1), "ms_per_step": round(1e3 * el / k, 3),
+                      "received_bytes_per_rank": recv, "gathered_GB_per_s_per_rank": round(recv * k / el / 1e9, 1), "steps": k}
+            del full
+        except Exception as exc:      # the headline measurement above is complete: report it whatever happens here
+            gather = {"error": repr(exc)}
 
     if rank == 0:
         achieved = BYTES_PER_CLIP * B / (kernel_avg_ms * 1e-3) / 1e9
