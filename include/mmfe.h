@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define MMFE_ABI_VERSION 1
+#define MMFE_ABI_VERSION 2
 
 /* error codes */
 #define MMFE_OK            0
@@ -83,6 +83,12 @@ extern "C" {
 #define MMFE_LAYOUT_TIME_MAJOR  0  /* out[row][frame][feature] */
 #define MMFE_LAYOUT_FEAT_MAJOR  1  /* out[row][feature][frame] */
 
+/* mmfe_spec.out_dtype: element type of the output tensor */
+#define MMFE_OUT_F32   0
+#define MMFE_OUT_F16   1  /* IEEE half, round to nearest even: what the encoders' @autocast() casts the spectrogram to
+                           (classification/vggsound/models/vit_model.py:388); n_fft 512 log-mel kernel only */
+#define MMFE_OUT_BF16  2  /* bfloat16, round to nearest even; n_fft 512 log-mel kernel only */
+
 typedef struct mmfe_spec {
     int32_t struct_size;   /* = sizeof(mmfe_spec) */
     int32_t kind;          /* MMFE_KIND_* */
@@ -108,6 +114,7 @@ typedef struct mmfe_spec {
     int32_t layout;        /* MMFE_LAYOUT_* */
     int32_t window_f64;    /* 1: the `window` argument of mmfe_plan_create points to doubles (librosa / scipy build
                               their windows in float64 and multiply in float64); 0: floats */
+    int32_t out_dtype;     /* MMFE_OUT_*: the arithmetic stays float32, only the stored value is rounded */
 } mmfe_spec;
 
 typedef struct mmfe_plan mmfe_plan;
@@ -143,18 +150,19 @@ int mmfe_plan_destroy(mmfe_plan* plan);
 /* Run the transform on a batch.
  *   in         device, n_rows rows of n_samples floats, row r at in + r * in_stride
  *   out        device, contiguous (n_rows, frames, feat) or (n_rows, feat, frames) per spec.layout,
- *              frames/feat as reported by mmfe_spec_out_shape (after out_frames / drop_last)
+ *              frames/feat as reported by mmfe_spec_out_shape (after out_frames / drop_last); elements of
+ *              spec.out_dtype (float unless stated otherwise)
  *   hip_stream hipStream_t or NULL
  * Stands where the reference calls kaldi.fbank (vggsound.py:45), librosa.stft + log
  * (epic_kitchen.py:119-125), scipy.signal.stft + abs (adbox.py:20) or frame_signal. */
 int mmfe_run(const mmfe_plan* plan, const float* in, int64_t in_stride, int64_t n_rows, int64_t n_samples,
-             float* out, void* hip_stream);
+             void* out, void* hip_stream);
 
 /* Same transform, but row r is the slice [offsets[r], offsets[r] + n_samples) of recording
  * rec_index[r] in a packed device buffer (recording i starts at recs + rec_start[i]).  Stands for
  * the slicing in EPICKitchen._extract_sound_feature (epic_kitchen.py:128-154) feeding _log_specgram. */
 int mmfe_run_slices(const mmfe_plan* plan, const float* recs, const int64_t* rec_start, const int32_t* rec_index,
-                    const int64_t* offsets, int64_t n_rows, int64_t n_samples, float* out, void* hip_stream);
+                    const int64_t* offsets, int64_t n_rows, int64_t n_samples, void* out, void* hip_stream);
 
 /* Sum and sum of squares (float64) of n device floats, accumulated into sums[0], sums[1] (device,
  * caller zeroes them).  Stands for the two DataLoader passes of cal_norm (vggsound.py:85-107). */

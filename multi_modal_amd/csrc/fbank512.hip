@@ -84,7 +84,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct FbankArgs {
     RowSource src;
-    float* out;
+    void* out;                 // elements of out_dtype
+    int out_dtype;             // MMFE_OUT_*
     int n_rows;
     int frames_valid;      // frames computed per row (<= natural frame count, <= out_rows)
     int out_rows;          // frames per row in the output tensor
@@ -406,27 +407,47 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
             apply_log_affine_block(vab, p.la);
             const int n_ok = p.frames_valid - t0;         // >= 1, wave-uniform
             const int q4 = lane & 3, f0 = lane & ~3;      // frame slot, first filter of the lane's block
-            float* orow = p.out + ((int64_t)cur_row * p.out_rows + t0 + q4) * p.n_mel + f0;
+            const int64_t oidx = ((int64_t)cur_row * p.out_rows + t0 + q4) * p.n_mel + f0;
 #ifdef MMFE_ABL_NOSTORE
             if (q4 < n_ok && vab[0] == 123.456f && vab[5] == 654.321f) {
 #else
             if (q4 < n_ok) {
 #endif
-                if (p.vec_out) {        // n_mel % 4 == 0 and an aligned tensor: blocks are whole
-                    if (f0 < p.n_mel) MMFE_OUT_STORE4(vab[0], vab[1], vab[2], vab[3], orow);
-                    if (NGB > 0 && 64 + f0 < p.n_mel) MMFE_OUT_STORE4(vab[4], vab[5], vab[6], vab[7], orow + 64);
-                } else {
+                if (p.out_dtype == MMFE_OUT_F32) {
+                    float* orow = static_cast<float*>(p.out) + oidx;
+                    if (p.vec_out) {        // n_mel % 4 == 0 and an aligned tensor: blocks are whole
+                        if (f0 < p.n_mel) MMFE_OUT_STORE4(vab[0], vab[1], vab[2], vab[3], orow);
+                        if (NGB > 0 && 64 + f0 < p.n_mel) MMFE_OUT_STORE4(vab[4], vab[5], vab[6], vab[7], orow + 64);
+                    } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (f0 + i < p.n_mel) orow[i] = vab[i];
-                        if (NGB > 0 && 64 + f0 + i < p.n_mel) orow[64 + i] = vab[4 + i];
+                        for (int i = 0; i < 4; ++i) {
+                            if (f0 + i < p.n_mel) orow[i] = vab[i];
+                            if (NGB > 0 && 64 + f0 + i < p.n_mel) orow[64 + i] = vab[4 + i];
+                        }
+                    }
+                } else {                    // 16-bit output: four values = one 8-byte store
+                    unsigned short hb[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) hb[i] = p.out_dtype == MMFE_OUT_F16 ? f16_bits(vab[i]) : bf16_bits(vab[i]);
+                    unsigned short* orow = static_cast<unsigned short*>(p.out) + oidx;
+                    if (p.vec_out) {
+                        if (f0 < p.n_mel)
+                            *reinterpret_cast<uint2*>(orow) = make_uint2(hb[0] | (unsigned)hb[1] << 16, hb[2] | (unsigned)hb[3] << 16);
+                        if (NGB > 0 && 64 + f0 < p.n_mel)
+                            *reinterpret_cast<uint2*>(orow + 64) = make_uint2(hb[4] | (unsigned)hb[5] << 16, hb[6] | (unsigned)hb[7] << 16);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            if (f0 + i < p.n_mel) orow[i] = hb[i];
+                            if (NGB > 0 && 64 + f0 + i < p.n_mel) orow[64 + i] = hb[4 + i];
+                        }
                     }
                 }
             }
         } else {
             const int t = t0 + fl;
             const bool valid = t < p.frames_valid;
-            float* orow = p.out + ((int64_t)cur_row * p.out_rows + t) * p.n_mel;
+            const int64_t oidx = ((int64_t)cur_row * p.out_rows + t) * p.n_mel;
             for (int j = 0; j < p.n_pass; ++j) {
                 const int m = 16 * j + b;
                 const float* pp = pbuf + s_mel_start[m];
@@ -435,7 +456,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
                 float acc = 0.f;
                 for (int i = 0; i < n; ++i) acc = fmaf(wp[16 * i], pp[i], acc);
                 const float val = apply_log_affine(acc, p.la, none_flag);
-                if (valid && m < p.n_mel) orow[m] = val;
+                if (valid && m < p.n_mel) {
+                    if (p.out_dtype == MMFE_OUT_F32) static_cast<float*>(p.out)[oidx + m] = val;
+                    else static_cast<unsigned short*>(p.out)[oidx + m] = p.out_dtype == MMFE_OUT_F16 ? f16_bits(val) : bf16_bits(val);
+                }
             }
         }
         MMFE_STAMP(7);
@@ -677,7 +701,7 @@ int fbank512_prepare(Plan& plan) {
 }
 
 int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames_natural,
-                    int64_t out_frames, float* out, hipStream_t stream) {
+                    int64_t out_frames, void* out, hipStream_t stream) {
     const mmfe_spec& s = plan.spec;
     const int64_t frames_valid = std::min(n_frames_natural, out_frames);
     if (n_rows <= 0 || frames_valid <= 0) return MMFE_OK;
@@ -695,6 +719,7 @@ int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
     a.hop = s.hop;
     a.win_len = s.win_len;
     a.n_mel = s.n_mel;
+    a.out_dtype = s.out_dtype;
     a.vec_out = (s.n_mel % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 1 : 0;
     a.preemph = s.preemph;
     a.mean_scale = s.remove_dc ? 1.0f / (float)s.win_len : 0.0f;

@@ -11,6 +11,7 @@
 #include "mmfe_internal.h"
 
 #include <algorithm>
+#include <cstring>
 
 namespace mmfe {
 
@@ -39,8 +40,9 @@ __global__ void __launch_bounds__(256) frame_kernel(const FrameArgs p) {
     }
 }
 
-__global__ void __launch_bounds__(256) fill_kernel(float* out, int64_t n_rows, int64_t out_frames, int64_t first_pad,
-                                                   int64_t n_feat, int layout, float value) {
+template <typename T>
+__global__ void __launch_bounds__(256) fill_kernel(T* out, int64_t n_rows, int64_t out_frames, int64_t first_pad,
+                                                   int64_t n_feat, int layout, T value) {
     const int64_t pad_frames = out_frames - first_pad;
     const int64_t per_row = pad_frames * n_feat;
     const int64_t total = n_rows * per_row;
@@ -120,12 +122,29 @@ int frame_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t
     return MMFE_OK;
 }
 
-int fill_pad_rows(float* out, int64_t n_rows, int64_t out_frames, int64_t first_pad_frame, int64_t n_feat, int layout,
+int fill_pad_rows(void* out, int out_dtype, int64_t n_rows, int64_t out_frames, int64_t first_pad_frame, int64_t n_feat, int layout,
                   float value, hipStream_t stream) {
     if (n_rows <= 0 || first_pad_frame >= out_frames) return MMFE_OK;
     const int64_t total = n_rows * (out_frames - first_pad_frame) * n_feat;
-    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, out, n_rows, out_frames,
-                       first_pad_frame, n_feat, layout, value);
+    if (out_dtype == MMFE_OUT_F32) {
+        hipLaunchKernelGGL(fill_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, stream, static_cast<float*>(out), n_rows,
+                           out_frames, first_pad_frame, n_feat, layout, value);
+    } else {
+        // the 16-bit pattern of the rounded value, computed on the host with the same round-to-nearest-even rule
+        unsigned short bits;
+        if (out_dtype == MMFE_OUT_F16) {
+            const _Float16 h = static_cast<_Float16>(value);
+            std::memcpy(&bits, &h, 2);
+        } else {
+            unsigned u;
+            std::memcpy(&u, &value, 4);
+            if ((u & 0x7fffffffu) > 0x7f800000u) u = (u | 0x400000u);
+            else u += 0x7fffu + ((u >> 16) & 1u);
+            bits = (unsigned short)(u >> 16);
+        }
+        hipLaunchKernelGGL(fill_kernel<unsigned short>, dim3(grid_for(total, 256)), dim3(256), 0, stream,
+                           static_cast<unsigned short*>(out), n_rows, out_frames, first_pad_frame, n_feat, layout, bits);
+    }
     MMFE_HIP_CHECK(hipGetLastError());
     return MMFE_OK;
 }

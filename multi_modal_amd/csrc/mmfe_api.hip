@@ -107,6 +107,7 @@ int validate_spec(const mmfe_spec* s) {
         if (s->pad_mode < MMFE_PAD_NONE || s->pad_mode > MMFE_PAD_REFLECT) { set_error("unknown pad_mode"); return MMFE_EINVAL; }
     }
     if (s->out_frames < 0) { set_error("out_frames must be >= 0"); return MMFE_EINVAL; }
+    if (s->out_dtype < MMFE_OUT_F32 || s->out_dtype > MMFE_OUT_BF16) { set_error("unknown out_dtype"); return MMFE_EINVAL; }
     return MMFE_OK;
 }
 
@@ -144,7 +145,8 @@ void free_plan(Plan* p) {
     delete p;
 }
 
-int run_common(const Plan* plan, const RowSource& src, int64_t n_rows, int64_t n_samples, float* out, void* hip_stream) {
+int run_common(const Plan* plan, const RowSource& src, int64_t n_rows, int64_t n_samples, void* out_any, void* hip_stream) {
+    float* out = static_cast<float*>(out_any);      // every kernel family but the n_fft 512 one stores floats (checked at plan creation)
     if (plan == nullptr) { set_error("plan is NULL"); return MMFE_EINVAL; }
     if (n_rows < 0 || n_samples < 0) { set_error("negative size"); return MMFE_EINVAL; }
     if (n_rows == 0) return MMFE_OK;
@@ -158,7 +160,7 @@ int run_common(const Plan* plan, const RowSource& src, int64_t n_rows, int64_t n
     if (!guard.ok) { set_error("cannot make device %d current", plan->device); return MMFE_EHIP; }
     hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
     switch (plan->impl) {
-        case IMPL_FBANK512: rc = fbank512_launch(*plan, src, n_rows, n_samples, natural, frames, out, stream); break;
+        case IMPL_FBANK512: rc = fbank512_launch(*plan, src, n_rows, n_samples, natural, frames, out_any, stream); break;
         case IMPL_DFT_GENERIC: rc = dftgen_launch(*plan, src, n_rows, n_samples, natural, frames, out, stream); break;
         case IMPL_RFFT400: rc = rfft400_launch(*plan, src, n_rows, n_samples, natural, frames, out, stream); break;
         case IMPL_STFT32: rc = stft32_launch(*plan, src, n_rows, n_samples, frames, out, stream); break;
@@ -168,7 +170,7 @@ int run_common(const Plan* plan, const RowSource& src, int64_t n_rows, int64_t n
     if (rc) return rc;
     if (natural < frames) {
         const float v = (s.pad_value + s.out_shift) * s.out_scale;
-        rc = fill_pad_rows(out, n_rows, frames, natural, feat, s.layout, v, stream);
+        rc = fill_pad_rows(out_any, s.out_dtype, n_rows, frames, natural, feat, s.layout, v, stream);
     }
     return rc;
 }
@@ -287,6 +289,10 @@ int mmfe_plan_create(const mmfe_spec* spec, const void* window, const int32_t* b
         default:
             rc = MMFE_EINVAL;
     }
+    if (rc == MMFE_OK && spec->out_dtype != MMFE_OUT_F32 && p->impl != IMPL_FBANK512) {
+        set_error("half-precision output is implemented by the n_fft 512 log-mel kernel only");
+        rc = MMFE_EINVAL;
+    }
     if (rc) { free_plan(p); return rc; }
     if (hipDeviceSynchronize() != hipSuccess) { set_error("table upload failed"); free_plan(p); return MMFE_EHIP; }
     *out_plan = reinterpret_cast<mmfe_plan*>(p);
@@ -301,7 +307,7 @@ int mmfe_plan_destroy(mmfe_plan* plan) {
     return MMFE_OK;
 }
 
-int mmfe_run(const mmfe_plan* plan, const float* in, int64_t in_stride, int64_t n_rows, int64_t n_samples, float* out,
+int mmfe_run(const mmfe_plan* plan, const float* in, int64_t in_stride, int64_t n_rows, int64_t n_samples, void* out,
              void* hip_stream) {
     if (in_stride < n_samples && n_rows > 1) { set_error("in_stride (%lld) smaller than n_samples (%lld)", (long long)in_stride, (long long)n_samples); return MMFE_EINVAL; }
     RowSource src{in, in_stride, nullptr, nullptr, nullptr};
@@ -309,7 +315,7 @@ int mmfe_run(const mmfe_plan* plan, const float* in, int64_t in_stride, int64_t 
 }
 
 int mmfe_run_slices(const mmfe_plan* plan, const float* recs, const int64_t* rec_start, const int32_t* rec_index,
-                    const int64_t* offsets, int64_t n_rows, int64_t n_samples, float* out, void* hip_stream) {
+                    const int64_t* offsets, int64_t n_rows, int64_t n_samples, void* out, void* hip_stream) {
     if (rec_start == nullptr || rec_index == nullptr || offsets == nullptr) { set_error("NULL slice table"); return MMFE_EINVAL; }
     const Plan* p = reinterpret_cast<const Plan*>(plan);
     if (p != nullptr && p->impl == IMPL_STFT32) { set_error("slices are not supported for STFT_MAG plans"); return MMFE_EINVAL; }

@@ -108,7 +108,7 @@ enum Impl { IMPL_FBANK512 = 1, IMPL_STFT32 = 2, IMPL_DFT_GENERIC = 3, IMPL_FRAME
 // launchers (one per translation unit)
 int fbank512_prepare(Plan& plan);
 int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames_natural,
-                    int64_t out_frames, float* out, hipStream_t stream);
+                    int64_t out_frames, void* out, hipStream_t stream);
 
 int stft32_prepare(Plan& plan);
 int stft32_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames,
@@ -130,10 +130,22 @@ int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64
 int frame_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames,
                  float* out, hipStream_t stream);
 
-int fill_pad_rows(float* out, int64_t n_rows, int64_t out_frames, int64_t first_pad_frame, int64_t n_feat, int layout,
+int fill_pad_rows(void* out, int out_dtype, int64_t n_rows, int64_t out_frames, int64_t first_pad_frame, int64_t n_feat, int layout,
                   float value, hipStream_t stream);
 
 int feature_sums_launch(const float* x, int64_t n, double* sums, hipStream_t stream);
+
+// Output element conversions (round to nearest even), as raw 16-bit patterns.
+__device__ __forceinline__ unsigned short f16_bits(float v) {
+    const _Float16 h = static_cast<_Float16>(v);
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ unsigned short bf16_bits(float v) {
+    unsigned u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);     // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
 
 // Launch-geometry helpers (thread-safe, cached per kernel and device).
 //   kernel_prepare: raises the kernel's dynamic-LDS limit to the CU's 160 KB on the current device (once) and

@@ -13,6 +13,9 @@ import torch
 
 from . import _native as N
 
+OUT_DTYPES = {N.OUT_F32: torch.float32, N.OUT_F16: torch.float16, N.OUT_BF16: torch.bfloat16}
+OUT_CODES = {v: k for k, v in OUT_DTYPES.items()}
+
 _plans: Dict[Hashable, N.Plan] = {}
 _plans_lock = threading.Lock()
 _last_kernel = "none"
@@ -71,11 +74,12 @@ def run_rows(plan: N.Plan, x: torch.Tensor, out: torch.Tensor = None) -> torch.T
     frames, feat = plan.out_shape(n)
     shape = (rows, frames, feat) if plan.spec.layout == N.LAYOUT_TIME_MAJOR or plan.spec.kind == N.KIND_FRAME \
         else (rows, feat, frames)
+    dtype = OUT_DTYPES[plan.spec.out_dtype]
     if out is None:
-        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        out = torch.empty(shape, dtype=dtype, device=x.device)
     else:
-        if tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
-            raise ValueError(f"out must be a contiguous float32 tensor of shape {shape} on {x.device}")
+        if tuple(out.shape) != shape or out.dtype != dtype or not out.is_contiguous() or out.device != x.device:
+            raise ValueError(f"out must be a contiguous {dtype} tensor of shape {shape} on {x.device}")
     if rows == 0 or frames == 0 or feat == 0:
         return out
     if x.device.index != plan.device:

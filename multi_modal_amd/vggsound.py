@@ -19,8 +19,11 @@ _KW = dict(sample_frequency=SAMPLE_RATE, window_type="hanning", num_mel_bins=NUM
            out_frames=TARGET_LENGTH, pad_value=0.0, out_shift=-NORM_MEAN, out_scale=1.0 / NORM_STD)
 
 
-def preprocessing_audio_batch(audio: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def preprocessing_audio_batch(audio: torch.Tensor, out: Optional[torch.Tensor] = None,
+                              dtype: torch.dtype = torch.float32) -> torch.Tensor:
     """(B, n) or (B, 1, n) waveforms -> (B, 384, 128) normalised log-mel, one launch per batch.
+    dtype=torch.float16 hands the encoder the tensor its @autocast() would cast to
+    (classification/vggsound/models/vit_model.py:388), without a float32 round trip through HBM.
     This is the call that replaces `batch[k].to(device)` of a collated spectrogram batch
     (classification/vggsound/vanilla_multi.py:90): workers hand over raw waveforms instead."""
     if audio.dim() == 3:
@@ -29,7 +32,7 @@ def preprocessing_audio_batch(audio: torch.Tensor, out: Optional[torch.Tensor] =
         audio = audio[:, 0, :]
     if audio.dim() != 2:
         raise ValueError(f"expected (B, n) or (B, 1, n), got {tuple(audio.shape)}")
-    return fbank_batch(audio, out=out, **_KW)
+    return fbank_batch(audio, out=out, dtype=dtype, **_KW)
 
 
 def preprocessing_audio(audio: torch.Tensor) -> torch.Tensor:

@@ -436,6 +436,23 @@ def test_fbank_n400_radix(mm, O):
     assert p999 <= 1e-4 and mx <= 2e-3
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_vggsound_half_precision_output(mm, dtype):
+    """16-bit output of the fused log-mel kernel = its float32 output rounded to nearest even, bit for bit (the
+    arithmetic is the same float32 pipeline), including padded rows, ragged lengths and a non-multiple-of-4 bank."""
+    clips = torch.from_numpy(np.stack([synth(k, 160000, 77 + i) for i, k in enumerate(KINDS)])).cuda()
+    ref = mm.preprocessing_audio_batch(clips)
+    got = mm.preprocessing_audio_batch(clips, dtype=dtype)
+    assert got.dtype == dtype and got.shape == ref.shape
+    assert torch.equal(got, ref.to(dtype))
+    short = clips[:, :12345]                     # 30 frames, the other 354 rows are padding
+    assert torch.equal(mm.preprocessing_audio_batch(short, dtype=dtype), mm.preprocessing_audio_batch(short).to(dtype))
+    kw = dict(sample_frequency=16000, num_mel_bins=23, frame_shift=10.0)
+    assert torch.equal(mm.fbank_batch(clips[:, :48000], dtype=dtype, **kw), mm.fbank_batch(clips[:, :48000], **kw).to(dtype))
+    with pytest.raises(mm.MmfeError, match="half-precision"):
+        mm.fbank_batch(clips[:, :48000], dtype=dtype, round_to_power_of_two=False, **kw)     # n_fft 400: float32 only
+
+
 def test_cal_norm(mm):
     rng = np.random.default_rng(0)
     f = torch.from_numpy(rng.standard_normal((7, 384, 128)).astype(np.float32) * 4.4 - 5.2)
