@@ -234,7 +234,6 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
 
         // ---- mel (optional), log, affine, store ------------------------------------------------
         const int nfeat = p.n_feat;
-        const int total = nfr * nfeat;
         float local_max = -INFINITY;
         for (int i = threadIdx.x; i < FR * nfeat; i += kThreads) {
             int f, m;
@@ -260,7 +259,6 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
             p.out[o] = v;
             if (p.rowmax != nullptr) local_max = fmaxf(local_max, v);      // clamp + affine happen in the second pass
         }
-        (void)total;
         if (p.rowmax != nullptr) {
             // wave max, then one atomic per wave
             for (int off = 32; off > 0; off >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, off));
