@@ -506,3 +506,37 @@ def test_full_size_properties_logmel(mm):
     assert torch.all(mn >= mx - 2.0 - 1e-6)
     assert torch.isfinite(big).all()
 
+
+@pytest.mark.parametrize("which", ["fbank512", "rfft400"])
+def test_radix_kernels_read_slices(mm, which):
+    """mmfe_run_slices through the radix kernels: rows given as (recording, offset) slices of packed recordings give
+    the same features as the same rows handed over as a strided batch (odd offsets: scalar-load variants)."""
+    from multi_modal_amd import kaldi, logmel
+    recs = [torch.from_numpy(synth("noise0.1", n, 500 + i)).cuda() for i, n in enumerate((50000, 33333, 41001))]
+    packed = torch.cat(recs)
+    starts = torch.tensor([0, 50000, 83333], dtype=torch.int64, device="cuda")
+    rec_index = [0, 2, 1, 1, 0, 2, 0]
+    offsets = [0, 1, 7, 1600, 12345, 17000, 25999]
+    n = 24000
+    rows = torch.stack([recs[r][o:o + n] for r, o in zip(rec_index, offsets)])
+    if which == "fbank512":
+        plan = kaldi._fbank_plan(0, sample_frequency=16000.0, frame_length=25.0, frame_shift=10.0, num_mel_bins=80,
+                                 window_type="povey", blackman_coeff=0.42, preemphasis_coefficient=0.97, remove_dc_offset=True,
+                                 round_to_power_of_two=True, low_freq=20.0, high_freq=0.0, use_log_fbank=True)
+    else:
+        plan = logmel._plan(0, 400, 160, 80, 16000, False)
+    assert plan.kernel == which
+    ref = mm.plans.run_rows(plan, rows)
+    got = torch.empty_like(ref)
+    d_index = torch.tensor(rec_index, dtype=torch.int32, device="cuda")
+    d_off = torch.tensor(offsets, dtype=torch.int64, device="cuda")
+    plan.run_slices_ptr(packed.data_ptr(), starts.data_ptr(), d_index.data_ptr(), d_off.data_ptr(), len(offsets), n,
+                        got.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    if which == "rfft400":
+        assert torch.equal(got, ref)          # same arithmetic, only the loads differ
+    else:
+        # slices take the scalar-load variant of the kernel, whose 16-slice frame walk sums the DC offset in another
+        # order than the 13-slice 8-byte-load variant: equal to float32 rounding, not bit for bit
+        assert (got - ref).abs().max().item() <= 5e-4
+
