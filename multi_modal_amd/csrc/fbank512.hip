@@ -426,20 +426,17 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
                         }
                     }
                 } else {                    // 16-bit output: four values = one 8-byte store
-                    unsigned short hb[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) hb[i] = p.out_dtype == MMFE_OUT_F16 ? f16_bits(vab[i]) : bf16_bits(vab[i]);
                     unsigned short* orow = static_cast<unsigned short*>(p.out) + oidx;
                     if (p.vec_out) {
                         if (f0 < p.n_mel)
-                            *reinterpret_cast<uint2*>(orow) = make_uint2(hb[0] | (unsigned)hb[1] << 16, hb[2] | (unsigned)hb[3] << 16);
+                            *reinterpret_cast<uint2*>(orow) = make_uint2(pack2_bits(vab[0], vab[1], p.out_dtype), pack2_bits(vab[2], vab[3], p.out_dtype));
                         if (NGB > 0 && 64 + f0 < p.n_mel)
-                            *reinterpret_cast<uint2*>(orow + 64) = make_uint2(hb[4] | (unsigned)hb[5] << 16, hb[6] | (unsigned)hb[7] << 16);
+                            *reinterpret_cast<uint2*>(orow + 64) = make_uint2(pack2_bits(vab[4], vab[5], p.out_dtype), pack2_bits(vab[6], vab[7], p.out_dtype));
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            if (f0 + i < p.n_mel) orow[i] = hb[i];
-                            if (NGB > 0 && 64 + f0 + i < p.n_mel) orow[64 + i] = hb[4 + i];
+                            if (f0 + i < p.n_mel) orow[i] = p.out_dtype == MMFE_OUT_F16 ? f16_bits(vab[i]) : bf16_bits(vab[i]);
+                            if (NGB > 0 && 64 + f0 + i < p.n_mel) orow[64 + i] = p.out_dtype == MMFE_OUT_F16 ? f16_bits(vab[4 + i]) : bf16_bits(vab[4 + i]);
                         }
                     }
                 }

@@ -147,6 +147,14 @@ __device__ __forceinline__ unsigned short bf16_bits(float v) {
     return (unsigned short)(u >> 16);
 }
 
+// Two values rounded and packed into one 32-bit word (low half = first value); bfloat16 uses gfx950's packed convert.
+__device__ __forceinline__ unsigned pack2_bits(float a, float b, int out_dtype) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    if (out_dtype == MMFE_OUT_BF16) return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+    return (unsigned)f16_bits(a) | (unsigned)f16_bits(b) << 16;
+}
+
 // Launch-geometry helpers (thread-safe, cached per kernel and device).
 //   kernel_prepare: raises the kernel's dynamic-LDS limit to the CU's 160 KB on the current device (once) and
 //   returns how many blocks of `threads` threads with `lds` bytes of dynamic LDS are resident per CU, and the CU count.
