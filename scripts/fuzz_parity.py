@@ -6,7 +6,8 @@
 Not part of the test suite (it takes a minute or two); it is the wide net behind the fixed cases of
 tests/test_gpu_parity.py.  Every case prints one line; the script exits non-zero on the first case outside its
 tolerance.  Tolerances are those of the fixed tests: kaldi log-mel p99.9 <= 1e-4 and max <= 2e-3, log-mel
-(n_fft 400) max <= 1e-4, HAR magnitudes max <= 1e-6, frame_signal exact.
+(n_fft 400) max <= 1e-4, EPIC log spectrogram max <= 1e-4, HAR magnitudes max <= 1e-6, frame_signal exact,
+16-bit output equal to the rounded float32 output.
 """
 import os
 import sys
@@ -40,7 +41,16 @@ def case_fbank(rng):
     got = mm.fbank(torch.from_numpy(x)[None].cuda(), sample_frequency=16000, **kw).cpu().numpy()
     assert got.shape == ref.shape, (got.shape, ref.shape)
     mx, p = stats(got - ref)
-    return f"fbank[{mm.plans.last_kernel() if ref.size else '-'}] n={n} {kind} {kw}", mx, p, (p <= 1e-4 and mx <= 2e-3)
+    ok = p <= 1e-4 and mx <= 2e-3
+    if not ok:
+        # two float32 evaluations of a spectrum with near-empty cells can differ by more than that from each other:
+        # judge both against the float64 evaluation of the same formula, as the fixed tests do
+        exact = O.kaldi_fbank(torch.from_numpy(x)[None], sample_frequency=16000, compute_dtype=torch.float64, **kw).numpy()
+        g_mx, g_p = stats(got - exact)
+        r_mx, r_p = stats(ref - exact)
+        ok = g_p <= max(1e-4, 1.5 * r_p) and g_mx <= max(2e-3, 1.5 * r_mx)
+        mx, p = g_mx, g_p
+    return f"fbank[{mm.plans.last_kernel() if ref.size else '-'}] n={n} {kind} {kw}", mx, p, ok
 
 
 def case_logmel(rng):
@@ -56,6 +66,29 @@ def case_logmel(rng):
     assert got.shape == ref.shape, (got.shape, ref.shape)
     mx, p = stats(got - ref)
     return f"logmel[{mm.plans.last_kernel() if ref.size else '-'}] n={n} hop={hop} mels={n_mels} off={off} {kind}", mx, p, mx <= 1e-4
+
+
+def case_epic(rng):
+    kind = rng.choice(["noise0.1", "uniform", "sine+noise", "quiet"])
+    n = int(rng.choice([30672, 30696, int(rng.integers(2000, 40000))]))
+    x = synth(kind, n, int(rng.integers(1 << 30)))
+    ref = O.log_specgram(x)
+    got = mm.log_specgram(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    mx, p = stats(got - ref)
+    return f"epic n={n} {kind}", mx, p, mx <= 1e-4
+
+
+def case_half(rng):
+    dtype = [torch.float16, torch.bfloat16][int(rng.integers(2))]
+    n = int(rng.integers(400, 170000))
+    b = int(rng.integers(1, 6))
+    x = torch.from_numpy(np.stack([synth("noise0.1", n, int(rng.integers(1 << 30))) for _ in range(b)])).cuda()
+    ref = mm.preprocessing_audio_batch(x).to(dtype)
+    got = mm.preprocessing_audio_batch(x, dtype=dtype)
+    ok = bool(torch.equal(got, ref))
+    mx = float((got.float() - ref.float()).abs().max())
+    return f"half {dtype} b={b} n={n}", mx, mx, ok
 
 
 def case_har(rng):
@@ -87,7 +120,7 @@ def main():
     cases = int(sys.argv[sys.argv.index("--cases") + 1]) if "--cases" in sys.argv else 200
     seed = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 0
     rng = np.random.default_rng(seed)
-    makers = [case_fbank, case_fbank, case_logmel, case_logmel, case_har, case_frame]
+    makers = [case_fbank, case_fbank, case_logmel, case_logmel, case_har, case_frame, case_epic, case_half]
     worst = {}
     for i in range(cases):
         fn = makers[i % len(makers)]
