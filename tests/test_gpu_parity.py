@@ -540,3 +540,36 @@ def test_radix_kernels_read_slices(mm, which):
         # order than the 13-slice 8-byte-load variant: equal to float32 rounding, not bit for bit
         assert (got - ref).abs().max().item() <= 5e-4
 
+
+
+def test_plans_shared_between_threads_and_streams(mm):
+    """One cached plan serves several host threads, each launching on a stream of its own (ctypes drops the GIL for the
+    call, so the launches really interleave): every thread gets the bits the serial calls gave."""
+    import threading
+    clips = [torch.from_numpy(np.stack([synth("noise0.1", 160000, 900 + 4 * t + i) for i in range(4)])).cuda() for t in range(4)]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    imu = [torch.randn(512, 6, 192, device="cuda", generator=g) for _ in range(4)]
+    want = [(mm.preprocessing_audio_batch(c), mm.stft_mag(x)) for c, x in zip(clips, imu)]
+    torch.cuda.synchronize()
+    got, errs = [None] * 4, []
+
+    def work(t):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(25):
+                    y = mm.preprocessing_audio_batch(clips[t])
+                    z = mm.stft_mag(imu[t])
+                s.synchronize()
+            got[t] = (y, z)
+        except Exception as e:      # surfaced by the assert below
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errs, errs
+    for t in range(4):
+        assert torch.equal(got[t][0], want[t][0]) and torch.equal(got[t][1], want[t][1])
