@@ -30,6 +30,8 @@
  *     calls exit().
  *   - All data pointers passed to mmfe_run* are DEVICE pointers owned by the caller (e.g.
  *     tensor.data_ptr()).  The library allocates only plan-lifetime constant tables.
+ *   - Input samples are float32, or (spec.in_dtype = MMFE_IN_S16) the signed 16-bit PCM the reference's audio
+ *     files hold, decoded in the kernel's loads; strides and offsets always count input elements.
  *   - mmfe_run* is asynchronous on the given HIP stream (NULL = the default stream); it never
  *     synchronises and never allocates.
  *   - Plans are immutable after creation and may be shared between threads and streams, with one
@@ -47,7 +49,7 @@
 extern "C" {
 #endif
 
-#define MMFE_ABI_VERSION 2
+#define MMFE_ABI_VERSION 3
 
 /* error codes */
 #define MMFE_OK            0
@@ -89,6 +91,14 @@ extern "C" {
                            (classification/vggsound/models/vit_model.py:388); n_fft 512 log-mel kernel only */
 #define MMFE_OUT_BF16  2  /* bfloat16, round to nearest even; n_fft 512 log-mel kernel only */
 
+/* mmfe_spec.in_dtype: element type of the input rows */
+#define MMFE_IN_F32   0
+#define MMFE_IN_S16   1  /* signed 16-bit PCM, sample value = s / 32768 (exact in float32): what torchaudio.load
+                           (classification/vggsound/dataset/vggsound.py:66) and librosa.load
+                           (classification/recognition/dataset/epic_kitchen.py:135) make of the 16-bit FLAC / pcm_s16le
+                           WAV files the reference stores (vggsound.py:120, recognition/dataset/extract_audio.py:9);
+                           FBANK and LOGSPEC kinds */
+
 typedef struct mmfe_spec {
     int32_t struct_size;   /* = sizeof(mmfe_spec) */
     int32_t kind;          /* MMFE_KIND_* */
@@ -115,6 +125,7 @@ typedef struct mmfe_spec {
     int32_t window_f64;    /* 1: the `window` argument of mmfe_plan_create points to doubles (librosa / scipy build
                               their windows in float64 and multiply in float64); 0: floats */
     int32_t out_dtype;     /* MMFE_OUT_*: the arithmetic stays float32, only the stored value is rounded */
+    int32_t in_dtype;      /* MMFE_IN_*: results are bit-identical to running on the decoded float32 samples */
 } mmfe_spec;
 
 typedef struct mmfe_plan mmfe_plan;
@@ -148,20 +159,21 @@ int mmfe_plan_create(const mmfe_spec* spec, const void* window,
 int mmfe_plan_destroy(mmfe_plan* plan);
 
 /* Run the transform on a batch.
- *   in         device, n_rows rows of n_samples floats, row r at in + r * in_stride
+ *   in         device, n_rows rows of n_samples samples (float, or int16_t when spec.in_dtype = MMFE_IN_S16), row r
+ *              starting in_stride elements after row r - 1
  *   out        device, contiguous (n_rows, frames, feat) or (n_rows, feat, frames) per spec.layout,
  *              frames/feat as reported by mmfe_spec_out_shape (after out_frames / drop_last); elements of
  *              spec.out_dtype (float unless stated otherwise)
  *   hip_stream hipStream_t or NULL
  * Stands where the reference calls kaldi.fbank (vggsound.py:45), librosa.stft + log
  * (epic_kitchen.py:119-125), scipy.signal.stft + abs (adbox.py:20) or frame_signal. */
-int mmfe_run(const mmfe_plan* plan, const float* in, int64_t in_stride, int64_t n_rows, int64_t n_samples,
+int mmfe_run(const mmfe_plan* plan, const void* in, int64_t in_stride, int64_t n_rows, int64_t n_samples,
              void* out, void* hip_stream);
 
 /* Same transform, but row r is the slice [offsets[r], offsets[r] + n_samples) of recording
- * rec_index[r] in a packed device buffer (recording i starts at recs + rec_start[i]).  Stands for
+ * rec_index[r] in a packed device buffer (recording i starts rec_start[i] elements into recs).  Stands for
  * the slicing in EPICKitchen._extract_sound_feature (epic_kitchen.py:128-154) feeding _log_specgram. */
-int mmfe_run_slices(const mmfe_plan* plan, const float* recs, const int64_t* rec_start, const int32_t* rec_index,
+int mmfe_run_slices(const mmfe_plan* plan, const void* recs, const int64_t* rec_start, const int32_t* rec_index,
                     const int64_t* offsets, int64_t n_rows, int64_t n_samples, void* out, void* hip_stream);
 
 /* Sum and sum of squares (float64) of n device floats, accumulated into sums[0], sums[1] (device,

@@ -17,13 +17,14 @@ _lib = None
 _lib_lock = threading.Lock()
 
 # --- constants mirrored from include/mmfe.h -------------------------------------------------------
-ABI_VERSION = 2
+ABI_VERSION = 3
 KIND_FBANK, KIND_LOGSPEC, KIND_STFT_MAG, KIND_FRAME = 1, 2, 3, 4
 PAD_NONE, PAD_ZERO, PAD_REFLECT = 0, 1, 2
 FRAMES_SNIP, FRAMES_CENTER, FRAMES_SCIPY, FRAMES_CEIL = 0, 1, 2, 3
 LOG_NONE, LOG_LN_MAX, LOG_LN_ADD, LOG_LOG10_MAX = 0, 1, 2, 3
 LAYOUT_TIME_MAJOR, LAYOUT_FEAT_MAJOR = 0, 1
 OUT_F32, OUT_F16, OUT_BF16 = 0, 1, 2
+IN_F32, IN_S16 = 0, 1
 
 EXPORTED_SYMBOLS = (
     "mmfe_abi_version", "mmfe_last_error", "mmfe_device_count", "mmfe_spec_out_shape",
@@ -62,6 +63,7 @@ class MmfeSpec(ctypes.Structure):
         ("layout", ctypes.c_int32),
         ("window_f64", ctypes.c_int32),
         ("out_dtype", ctypes.c_int32),
+        ("in_dtype", ctypes.c_int32),
     ]
 
 
@@ -131,7 +133,8 @@ def make_spec(**kw) -> MmfeSpec:
     s.struct_size = ctypes.sizeof(MmfeSpec)
     defaults = dict(win_off=0, pad_mode=PAD_NONE, frames_mode=FRAMES_SNIP, n_mel=0, remove_dc=0, preemph=0.0, power=2,
                     spec_scale=1.0, log_kind=LOG_NONE, log_floor=0.0, out_shift=0.0, out_scale=1.0, out_frames=0,
-                    pad_value=0.0, drop_last=0, clamp_below_max=0.0, layout=LAYOUT_TIME_MAJOR, n_fft=0, window_f64=0, out_dtype=OUT_F32)
+                    pad_value=0.0, drop_last=0, clamp_below_max=0.0, layout=LAYOUT_TIME_MAJOR, n_fft=0, window_f64=0, out_dtype=OUT_F32,
+                    in_dtype=IN_F32)
     defaults.update(kw)
     for k, v in defaults.items():
         setattr(s, k, v)

@@ -56,6 +56,7 @@ struct DftArgs {
     const float* band_w;
 };
 
+template <typename S /* input element: float, or int16_t PCM decoded as s / 32768 */>
 __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2* s_tw = reinterpret_cast<double2*>(smem);                     // 2*n_fft half-step twiddles
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
         const int row = (int)(work / blocks_per_row);
         const int t0 = (int)(work - (int64_t)row * blocks_per_row) * FR;
         const int nfr = min(FR, p.frames_valid - t0);
-        const float* rp = row_ptr(p.src, row);
+        const S* rp = row_ptr_as<S>(p.src, row);
 
         // barriers order LDS only: the previous item's output stores stay in flight instead of being waited for
         lds_barrier();   // previous work item is done with s_u / s_p (and s_tw is loaded)
@@ -106,7 +107,7 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
             const int hi_s = (t0 + FR - 1) * p.hop + p.centre_shift + p.win_len;
             const bool interior = nfr == FR && lo_s >= 0 && hi_s <= p.n_samples;              // block-uniform
             if (interior) {
-                const float* fp = rp + base;
+                const S* fp = rp + base;
                 const bool pre = p.preemph != 0.f && !p.remove_dc;
                 for (int j0 = threadIdx.x / FR; j0 < p.win_len; j0 += kSweep * kRows) {
                     float x[kSweep], xp[kSweep];
@@ -114,8 +115,8 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
                     for (int u = 0; u < kSweep; ++u) {
                         const int j = j0 + u * kRows;
                         const int jc = j < p.win_len ? j : 0;
-                        x[u] = fp[jc];
-                        xp[u] = pre ? fp[jc > 0 ? jc - 1 : 0] : 0.f;
+                        x[u] = sample_value(fp[jc]);
+                        xp[u] = pre ? sample_value(fp[jc > 0 ? jc - 1 : 0]) : 0.f;
                     }
 #pragma unroll
                     for (int u = 0; u < kSweep; ++u) {
@@ -395,11 +396,14 @@ int dftgen_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
         return MMFE_EINVAL;
     }
     int resident = 1, cus = 256;      // persistent blocks: as many as fit at once, so that every block gets the same share of the work
-    int rc = kernel_prepare(reinterpret_cast<const void*>(&dftgen_kernel), kThreads, lds, &resident, &cus);
+    const bool pcm = s.in_dtype == MMFE_IN_S16;
+    const void* fn = pcm ? reinterpret_cast<const void*>(&dftgen_kernel<int16_t>) : reinterpret_cast<const void*>(&dftgen_kernel<float>);
+    int rc = kernel_prepare(fn, kThreads, lds, &resident, &cus);
     if (rc) return rc;
     const int64_t work = n_rows * ((frames_valid + FR - 1) / FR);
     const int grid = (int)std::min<int64_t>(work, (int64_t)cus * resident);
-    hipLaunchKernelGGL(dftgen_kernel, dim3(grid), dim3(kThreads), lds, stream, a);
+    if (pcm) hipLaunchKernelGGL(dftgen_kernel<int16_t>, dim3(grid), dim3(kThreads), lds, stream, a);
+    else hipLaunchKernelGGL(dftgen_kernel<float>, dim3(grid), dim3(kThreads), lds, stream, a);
     MMFE_HIP_CHECK(hipGetLastError());
     if (clamp) return clamp_affine_launch(plan, out, n_rows, out_frames * a.n_feat, stream);
     return MMFE_OK;

@@ -61,12 +61,6 @@ typedef float mmfe_f32x4 __attribute__((ext_vector_type(4)));
 #define MMFE_OUT_STORE4(a, b, c, d, ptr) (*reinterpret_cast<mmfe_f32x4*>(ptr) = mmfe_f32x4{(a), (b), (c), (d)})
 #endif
 
-#ifndef MMFE_PREFETCH_AT
-#define MMFE_PREFETCH_AT 1   // 0: after the first-half transpose write, 1: after the second-half spectrum write
-#endif
-#ifndef MMFE_PREFETCH_EARLY
-#define MMFE_PREFETCH_EARLY 6
-#endif
 #ifndef MMFE_TWIDDLE_REGS
 #define MMFE_TWIDDLE_REGS 1   // 1: first-half twiddles live in 30 VGPRs instead of LDS
 #endif
@@ -112,17 +106,37 @@ struct FbankArgs {
     unsigned long long* stamps;  // diagnostic build only
 };
 
+// Input element types.  A lane holds its 2-sample slices as they come from memory: two floats, or one 32-bit word
+// with two 16-bit PCM samples (half the prefetch registers).  PCM samples enter the pipeline as their integer values;
+// the 1/32768 of the decode is folded into the window table, which is exact (every stage before the window is
+// linear and a power-of-two scale commutes with float rounding), so the results equal those of decoded floats.
+template <bool PCM> struct Input;
+template <> struct Input<false> {
+    typedef float elem;
+    typedef float2 slice;
+    static __device__ __forceinline__ float2 unpack(float2 v) { return v; }
+    static __device__ __forceinline__ float2 perturb(float2 v, int nt) { return make_float2(v.y * 1.0001f, v.x + 1e-3f * (float)nt); }
+};
+template <> struct Input<true> {
+    typedef int16_t elem;
+    typedef uint32_t slice;
+    static __device__ __forceinline__ float2 unpack(uint32_t v) {
+        return make_float2((float)(int16_t)(v & 0xffffu), (float)((int32_t)v >> 16));
+    }
+    static __device__ __forceinline__ uint32_t perturb(uint32_t v, int nt) { return v * 2654435761u + (uint32_t)nt; }
+};
+
 // Loads the 2-sample slices (32a+2b, 32a+2b+1), a = 0..NA-1, of one frame.  Branch-free, so the
 // surrounding loop stays one basic block and the loads can be scheduled freely: a frame slot beyond
 // the row's last frame reads row 0 instead (`safe`; its results are never stored), and lanes of a
 // slice that sits in the zero padding read `safe` and select zero.  EXACT promises
 // 32*(NA-1) < win_len <= 32*NA, so only the last slice needs the per-lane test and all other loads
 // are one base register plus an immediate offset.  The VEC2 form needs an even win_len.
-template <int NA, bool VEC2, bool EXACT, int A0 = 0, int A1 = NA>
+template <int NA, bool VEC2, bool EXACT>
 __device__ __forceinline__ void load_frame(float2 (&v)[NA], const float* fp, const float* safe, bool valid, int b, int win_len) {
     const float* base = (valid ? fp : safe) + 2 * b;
 #pragma unroll
-    for (int a = A0; a < A1; ++a) {
+    for (int a = 0; a < NA; ++a) {
         const int idx = 32 * a + 2 * b;
         const bool whole = EXACT && a < NA - 1;        // compile-time: slice entirely inside the window
         if (VEC2) {
@@ -144,6 +158,27 @@ __device__ __forceinline__ void load_frame(float2 (&v)[NA], const float* fp, con
     }
 }
 
+// The same for 16-bit PCM: one 4-byte load per slice (VEC2: needs 4-byte aligned frame starts) or two 2-byte loads.
+template <int NA, bool VEC2, bool EXACT>
+__device__ __forceinline__ void load_frame(uint32_t (&v)[NA], const int16_t* fp, const int16_t* safe, bool valid, int b, int win_len) {
+    const int16_t* base = (valid ? fp : safe) + 2 * b;
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        const int idx = 32 * a + 2 * b;
+        const bool whole = EXACT && a < NA - 1;
+        if (VEC2) {
+            const bool ok = whole || idx + 1 < win_len;
+            const uint32_t r = *reinterpret_cast<const uint32_t*>(ok ? base + 32 * a : safe);
+            v[a] = whole ? r : (ok ? r : 0u);
+        } else {
+            const bool ok0 = whole || idx < win_len, ok1 = whole || idx + 1 < win_len;
+            const uint32_t r0 = *reinterpret_cast<const uint16_t*>(ok0 ? base + 32 * a : safe);
+            const uint32_t r1 = *reinterpret_cast<const uint16_t*>(ok1 ? base + 32 * a + 1 : safe);
+            v[a] = (ok0 ? r0 : 0u) | (ok1 ? r1 : 0u) << 16;
+        }
+    }
+}
+
 // Diagnostic build only (-DMMFE_STAMPS): per-phase s_memtime shares of the main loop, printed by the launcher.
 #ifdef MMFE_STAMPS
 #define MMFE_STAMP(i)                                                                                   \
@@ -159,8 +194,10 @@ __device__ __forceinline__ void load_frame(float2 (&v)[NA], const float* fp, con
 #define MMFE_STAMP(i) do { } while (0)
 #endif
 
-template <int NA /* ceil(win_len/32) */, bool VEC2, bool EXACT, int NGA, int NGB /* groups of 4 bins per mel set; NGA == 0: VALU mel */>
+template <bool PCM, int NA /* ceil(win_len/32) */, bool VEC2, bool EXACT, int NGA, int NGB /* groups of 4 bins per mel set; NGA == 0: VALU mel */>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_SIMD) fbank512_kernel(const FbankArgs p) {
+    typedef Input<PCM> In;
+    typedef typename In::elem Elem;
     constexpr bool kMfmaMel = NGA > 0;
     constexpr int kStepsA = 4 * NGA, kStepsB = 4 * NGB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -217,7 +254,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
         if (qq >= qpr) { qq -= qpr; r += 1; }
     };
 
-    const float* safe = row_ptr(p.src, 0);      // first samples of row 0: always readable
+    const Elem* safe = row_ptr_as<Elem>(p.src, 0);      // first samples of row 0: always readable
 #if MMFE_TWIDDLE_REGS
     float2 twr[15];                             // W256^(b*c), c = 1..15: resident for the life of the kernel
 #pragma unroll
@@ -225,11 +262,11 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
 #endif
     float none_flag = p.la.none_flag;
     asm volatile("" : "+v"(none_flag));         // a per-lane value from here on: selects on it stay v_cndmask
-    float2 nxt[NA];
+    typename In::slice nxt[NA];
     {
         const int t = (int)q * 4 + fl;
         const bool valid = row < (unsigned)p.n_rows && t < p.frames_valid;
-        const float* fp = row_ptr(p.src, valid ? row : 0) + (int64_t)t * p.hop;
+        const Elem* fp = row_ptr_as<Elem>(p.src, valid ? row : 0) + (int64_t)t * p.hop;
         load_frame<NA, VEC2, EXACT>(nxt, fp, safe, valid, b, p.win_len);
     }
 
@@ -243,7 +280,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
 
         float2 g[NA];
 #pragma unroll
-        for (int a = 0; a < NA; ++a) g[a] = nxt[a];
+        for (int a = 0; a < NA; ++a) g[a] = In::unpack(nxt[a]);
 
         // ---- per-frame DC removal (kaldi remove_dc_offset) ------------------------------------
         {
@@ -291,32 +328,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
             fbuf[c * 17 + b] = val;
         }
         wave_lds_fence();
-        // prefetch the next quad of this wave here, where register pressure is lowest (the first-half
-        // registers are dead); the loads stay in flight under the second half of this iteration
         MMFE_STAMP(2);
-#if MMFE_PREFETCH_AT == 2
-        // split prefetch: the first MMFE_PREFETCH_EARLY slices of the next quad are requested here, ahead of the
-        // second half (as many as the register budget leaves room for), the rest after it
-        advance(row, q);
-        const int nt_e = (int)q * 4 + fl;
-        const bool nvalid_e = row < (unsigned)p.n_rows && nt_e < p.frames_valid;
-        const float* nfp_e = row_ptr(p.src, row < (unsigned)p.n_rows ? row : 0) + (int64_t)nt_e * p.hop;
-        load_frame<NA, VEC2, EXACT, 0, (MMFE_PREFETCH_EARLY < NA ? MMFE_PREFETCH_EARLY : NA)>(nxt, nfp_e, safe, nvalid_e, b, p.win_len);
-#endif
-#if MMFE_PREFETCH_AT == 0
-        advance(row, q);
-        {
-            const int nt = (int)q * 4 + fl;
-            const bool nvalid = row < (unsigned)p.n_rows && nt < p.frames_valid;
-            const float* nfp = row_ptr(p.src, row < (unsigned)p.n_rows ? row : 0) + (int64_t)nt * p.hop;
-#ifdef MMFE_ABL_NOLOAD
-#pragma unroll
-            for (int a = 0; a < NA; ++a) nxt[a] = make_float2(nxt[a].y * 1.0001f, nxt[a].x + 1e-3f * (float)nt);
-#else
-            load_frame<NA, VEC2, EXACT>(nxt, nfp, safe, nvalid, b, p.win_len);
-#endif
-        }
-#endif
         float2 u[16];
 #pragma unroll
         for (int bb = 0; bb < 16; ++bb) u[bb] = fbuf[b * 17 + bb];
@@ -332,23 +344,20 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
         wave_lds_fence();
 
         // ---- real-FFT recombination on pairs (k, 256-k), power spectrum ------------------------
-#if MMFE_PREFETCH_AT == 2
-        load_frame<NA, VEC2, EXACT, (MMFE_PREFETCH_EARLY < NA ? MMFE_PREFETCH_EARLY : NA), NA>(nxt, nfp_e, safe, nvalid_e, b, p.win_len);
-#endif
-#if MMFE_PREFETCH_AT == 1
+        // prefetch the next quad of this wave here, where register pressure is lowest (both FFT halves are done
+        // and only Z in LDS is live); the loads stay in flight under the rest of this iteration
         advance(row, q);
         {
             const int nt = (int)q * 4 + fl;
             const bool nvalid = row < (unsigned)p.n_rows && nt < p.frames_valid;
-            const float* nfp = row_ptr(p.src, row < (unsigned)p.n_rows ? row : 0) + (int64_t)nt * p.hop;
+            const Elem* nfp = row_ptr_as<Elem>(p.src, row < (unsigned)p.n_rows ? row : 0) + (int64_t)nt * p.hop;
 #ifdef MMFE_ABL_NOLOAD
 #pragma unroll
-            for (int a = 0; a < NA; ++a) nxt[a] = make_float2(nxt[a].y * 1.0001f, nxt[a].x + 1e-3f * (float)nt);
+            for (int a = 0; a < NA; ++a) nxt[a] = In::perturb(nxt[a], nt);
 #else
             load_frame<NA, VEC2, EXACT>(nxt, nfp, safe, nvalid, b, p.win_len);
 #endif
         }
-#endif
         MMFE_STAMP(4);
         float pk[8], pq[8];
 #pragma unroll
@@ -471,10 +480,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
 #endif
 }
 
-template <int NA, bool VEC2, bool EXACT, int NGA, int NGB>
+template <bool PCM, int NA, bool VEC2, bool EXACT, int NGA, int NGB>
 int launch_variant(const FbankArgs& args, int grid, size_t lds, hipStream_t stream) {
     int resident = 0, cus = 0;      // raises the variant's dynamic-LDS limit on this device (once); the grid is sized by the caller
-    const int prc = kernel_prepare(reinterpret_cast<const void*>(&fbank512_kernel<NA, VEC2, EXACT, NGA, NGB>), 64 * kWavesPerBlock, lds,
+    const int prc = kernel_prepare(reinterpret_cast<const void*>(&fbank512_kernel<PCM, NA, VEC2, EXACT, NGA, NGB>), 64 * kWavesPerBlock, lds,
                                    &resident, &cus);
     if (prc) return prc;
 #ifdef MMFE_STAMPS
@@ -482,7 +491,7 @@ int launch_variant(const FbankArgs& args, int grid, size_t lds, hipStream_t stre
     const size_t n_st = (size_t)grid * kWavesPerBlock * 8;
     MMFE_HIP_CHECK(hipMalloc((void**)&targs.stamps, n_st * 8));
     MMFE_HIP_CHECK(hipMemset(targs.stamps, 0, n_st * 8));
-    hipLaunchKernelGGL((fbank512_kernel<NA, VEC2, EXACT, NGA, NGB>), dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, targs);
+    hipLaunchKernelGGL((fbank512_kernel<PCM, NA, VEC2, EXACT, NGA, NGB>), dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, targs);
     MMFE_HIP_CHECK(hipDeviceSynchronize());
     std::vector<unsigned long long> h(n_st);
     MMFE_HIP_CHECK(hipMemcpy(h.data(), targs.stamps, n_st * 8, hipMemcpyDeviceToHost));
@@ -498,7 +507,7 @@ int launch_variant(const FbankArgs& args, int grid, size_t lds, hipStream_t stre
     }
     return MMFE_OK;
 #else
-    hipLaunchKernelGGL((fbank512_kernel<NA, VEC2, EXACT, NGA, NGB>), dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, args);
+    hipLaunchKernelGGL((fbank512_kernel<PCM, NA, VEC2, EXACT, NGA, NGB>), dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, args);
     MMFE_HIP_CHECK(hipGetLastError());
     return MMFE_OK;
 #endif
@@ -620,8 +629,10 @@ int fbank512_prepare(Plan& plan) {
         return MMFE_EINVAL;
     }
     // window: pre-halved (folds the 1/2 of the real-FFT recombination; exact in binary fp), zero padded
+    // 16-bit PCM samples run through the pipeline as integers: their 1/32768 rides on the window as well
+    const float wscale = s.in_dtype == MMFE_IN_S16 ? 0.5f / 32768.0f : 0.5f;
     std::vector<float> win(512, 0.f);
-    for (int i = 0; i < s.win_len; ++i) win[i] = 0.5f * plan.window[i];
+    for (int i = 0; i < s.win_len; ++i) win[i] = wscale * plan.window[i];
     int rc = upload(&plan.d_window, win);
     if (rc) return rc;
     std::vector<float> tws(2 * 256), twp(2 * kTwPostEntries);
@@ -753,17 +764,23 @@ int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
     }
     const int grid = (int)std::min<int64_t>(want, (int64_t)cus * per_cu);
 
-    // 8-byte lane loads need every frame start to be 8-byte aligned
-    bool vec2 = (s.hop % 2 == 0) && (s.win_len % 2 == 0) && (reinterpret_cast<uintptr_t>(src.base) % 8 == 0);
+    // one load per 2-sample slice needs every frame start aligned to the slice (8 bytes of floats, 4 of PCM)
+    const bool pcm = s.in_dtype == MMFE_IN_S16;
+    bool vec2 = (s.hop % 2 == 0) && (s.win_len % 2 == 0) && (reinterpret_cast<uintptr_t>(src.base) % (pcm ? 4 : 8) == 0);
     if (src.offsets == nullptr) vec2 = vec2 && (src.stride % 2 == 0);
     else vec2 = false;   // slice offsets are data: take the scalar-load variant
     const int na = (s.win_len + 31) / 32;
     const int nga = plan.mel4_nga, ngb = plan.mel4_ngb;
 #define MMFE_FBANK_DISPATCH(NGA_, NGB_)                                                                         \
     if (nga == NGA_ && ngb == NGB_) {                                                                           \
-        if (na == 13 && vec2) return launch_variant<13, true, true, NGA_, NGB_>(a, grid, lds, stream);          \
-        return vec2 ? launch_variant<16, true, false, NGA_, NGB_>(a, grid, lds, stream)                         \
-                    : launch_variant<16, false, false, NGA_, NGB_>(a, grid, lds, stream);                       \
+        if (pcm) {                                                                                              \
+            if (na == 13 && vec2) return launch_variant<true, 13, true, true, NGA_, NGB_>(a, grid, lds, stream); \
+            return vec2 ? launch_variant<true, 16, true, false, NGA_, NGB_>(a, grid, lds, stream)               \
+                        : launch_variant<true, 16, false, false, NGA_, NGB_>(a, grid, lds, stream);             \
+        }                                                                                                       \
+        if (na == 13 && vec2) return launch_variant<false, 13, true, true, NGA_, NGB_>(a, grid, lds, stream);   \
+        return vec2 ? launch_variant<false, 16, true, false, NGA_, NGB_>(a, grid, lds, stream)                  \
+                    : launch_variant<false, 16, false, false, NGA_, NGB_>(a, grid, lds, stream);                \
     }
     MMFE_FBANK_DISPATCH(2, 7)
     MMFE_FBANK_DISPATCH(3, 8)

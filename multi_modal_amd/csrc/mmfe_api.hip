@@ -108,6 +108,11 @@ int validate_spec(const mmfe_spec* s) {
     }
     if (s->out_frames < 0) { set_error("out_frames must be >= 0"); return MMFE_EINVAL; }
     if (s->out_dtype < MMFE_OUT_F32 || s->out_dtype > MMFE_OUT_BF16) { set_error("unknown out_dtype"); return MMFE_EINVAL; }
+    if (s->in_dtype != MMFE_IN_F32 && s->in_dtype != MMFE_IN_S16) { set_error("unknown in_dtype"); return MMFE_EINVAL; }
+    if (s->in_dtype != MMFE_IN_F32 && s->kind != MMFE_KIND_FBANK && s->kind != MMFE_KIND_LOGSPEC) {
+        set_error("16-bit PCM input is implemented for the FBANK and LOGSPEC kinds only");
+        return MMFE_EINVAL;
+    }
     return MMFE_OK;
 }
 
@@ -307,14 +312,14 @@ int mmfe_plan_destroy(mmfe_plan* plan) {
     return MMFE_OK;
 }
 
-int mmfe_run(const mmfe_plan* plan, const float* in, int64_t in_stride, int64_t n_rows, int64_t n_samples, void* out,
+int mmfe_run(const mmfe_plan* plan, const void* in, int64_t in_stride, int64_t n_rows, int64_t n_samples, void* out,
              void* hip_stream) {
     if (in_stride < n_samples && n_rows > 1) { set_error("in_stride (%lld) smaller than n_samples (%lld)", (long long)in_stride, (long long)n_samples); return MMFE_EINVAL; }
     RowSource src{in, in_stride, nullptr, nullptr, nullptr};
     return run_common(reinterpret_cast<const Plan*>(plan), src, n_rows, n_samples, out, hip_stream);
 }
 
-int mmfe_run_slices(const mmfe_plan* plan, const float* recs, const int64_t* rec_start, const int32_t* rec_index,
+int mmfe_run_slices(const mmfe_plan* plan, const void* recs, const int64_t* rec_start, const int32_t* rec_index,
                     const int64_t* offsets, int64_t n_rows, int64_t n_samples, void* out, void* hip_stream) {
     if (rec_start == nullptr || rec_index == nullptr || offsets == nullptr) { set_error("NULL slice table"); return MMFE_EINVAL; }
     const Plan* p = reinterpret_cast<const Plan*>(plan);

@@ -23,27 +23,36 @@ void set_error(const char* fmt, ...);
 
 // Where the rows of a batch live.  Either a strided 2-D array, or slices of packed recordings.
 struct RowSource {
-    const float* base;         // strided: row r at base + r*stride.  slices: packed recordings
+    const void* base;          // strided: row r starts r*stride elements in.  slices: packed recordings.  Elements are
+                               // floats or int16_t PCM, as the plan's in_dtype says
     int64_t stride;
     const int64_t* rec_start;  // slices only (device)
     const int32_t* rec_index;  // slices only (device)
     const int64_t* offsets;    // slices only (device)
 };
 
-__device__ __forceinline__ const float* row_ptr(const RowSource& s, int64_t r) {
-    if (s.offsets == nullptr) return s.base + r * s.stride;
-    return s.base + s.rec_start[s.rec_index[r]] + s.offsets[r];
+template <typename S>
+__device__ __forceinline__ const S* row_ptr_as(const RowSource& s, int64_t r) {
+    const S* b = static_cast<const S*>(s.base);
+    if (s.offsets == nullptr) return b + r * s.stride;
+    return b + s.rec_start[s.rec_index[r]] + s.offsets[r];
 }
+__device__ __forceinline__ const float* row_ptr(const RowSource& s, int64_t r) { return row_ptr_as<float>(s, r); }
+
+// Value of a stored sample: floats as they are, 16-bit PCM as s / 32768 (exact in float32).
+__device__ __forceinline__ float sample_value(float v) { return v; }
+__device__ __forceinline__ float sample_value(int16_t v) { return (float)v * (1.0f / 32768.0f); }
 
 // Sample i of a row of n samples under the plan's padding rule (i may lie outside the row).
-__device__ __forceinline__ float fetch_sample(const float* row, int i, int n, int pad_mode) {
-    if (i >= 0 && i < n) return row[i];
+template <typename S>
+__device__ __forceinline__ float fetch_sample(const S* row, int i, int n, int pad_mode) {
+    if (i >= 0 && i < n) return sample_value(row[i]);
     if (pad_mode == MMFE_PAD_REFLECT) {
-        if (n == 1) return row[0];
+        if (n == 1) return sample_value(row[0]);
         const int period = 2 * (n - 1);
         int m = i % period;
         if (m < 0) m += period;
-        return row[m < n ? m : period - m];
+        return sample_value(row[m < n ? m : period - m]);
     }
     return 0.f;
 }

@@ -493,7 +493,7 @@ bool rfft400_supports(const mmfe_spec& s) {
     if (const char* f = std::getenv("MMFE_FORCE_GENERIC")) {
         if (std::string(f) == "1") return false;
     }
-    return s.n_fft == kN && s.n_mel > 0 && s.n_mel <= 128 && s.power == 2 && s.spec_scale == 1.0f && !s.window_f64 &&
+    return s.in_dtype == MMFE_IN_F32 && s.n_fft == kN && s.n_mel > 0 && s.n_mel <= 128 && s.power == 2 && s.spec_scale == 1.0f && !s.window_f64 &&
            !s.remove_dc && s.preemph == 0.f && s.hop >= 1 && s.hop <= kMaxHop && !(s.clamp_below_max > 0.f && !(s.out_scale > 0.f)) &&
            (s.frames_mode == MMFE_FRAMES_CENTER || s.frames_mode == MMFE_FRAMES_SNIP);
 }

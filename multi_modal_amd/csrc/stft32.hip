@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(kMaxThreads) stft32_kernel(const StftArgs p) {
     auto fetch = [&](int grp) {
         const int row0 = grp * R;
         const int rows = min(R, p.n_rows - row0);
-        const float4* g4 = reinterpret_cast<const float4*>(p.src.base + (int64_t)row0 * T);
+        const float4* g4 = reinterpret_cast<const float4*>(static_cast<const float*>(p.src.base) + (int64_t)row0 * T);
 #pragma unroll
         for (int q = 0; q < kPrefetch; ++q) {
             const int i = threadIdx.x + q * nthr;
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(kMaxThreads) stft32_kernel(const StftArgs p) {
                 }
             }
         } else if (p.vec_in) {
-            const float4* g4 = reinterpret_cast<const float4*>(p.src.base + (int64_t)row0 * T);
+            const float4* g4 = reinterpret_cast<const float4*>(static_cast<const float*>(p.src.base) + (int64_t)row0 * T);
             for (int i = threadIdx.x; i < rows * T4; i += nthr) {
                 const int r = i / T4;
                 const int j4 = i - r * T4;

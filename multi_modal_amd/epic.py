@@ -15,7 +15,7 @@ import torch
 
 from . import _native as N
 from . import melbank
-from .plans import cached_plan, require_gpu, run_rows, to_device_rows
+from .plans import IN_CODES, cached_plan, require_gpu, run_rows, to_device_rows
 
 N_FFT = 511               # epic_kitchen.py:119
 RESAMPLING_RATE = 24000   # epic_kitchen.py:77
@@ -23,8 +23,8 @@ HALF_SPAN_SEC = 0.639     # epic_kitchen.py:131-132
 EDGE_SEC = 1.279          # epic_kitchen.py:147,150
 
 
-def _logspec_plan(device: int, nperseg: int, hop: int, eps: float, out_scale: float) -> N.Plan:
-    key = ("epic", nperseg, hop, float(eps), float(out_scale))
+def _logspec_plan(device: int, nperseg: int, hop: int, eps: float, out_scale: float, in_dtype: int = N.IN_F32) -> N.Plan:
+    key = ("epic", nperseg, hop, float(eps), float(out_scale), int(in_dtype))
 
     def build(dev: int) -> N.Plan:
         if nperseg > N_FFT:
@@ -32,7 +32,7 @@ def _logspec_plan(device: int, nperseg: int, hop: int, eps: float, out_scale: fl
         spec = N.make_spec(kind=N.KIND_LOGSPEC, n_fft=N_FFT, win_len=nperseg, win_off=(N_FFT - nperseg) // 2, hop=hop,
                            pad_mode=N.PAD_ZERO, frames_mode=N.FRAMES_CENTER, n_mel=0, power=2,
                            log_kind=N.LOG_LN_ADD, log_floor=float(eps), out_shift=0.0, out_scale=out_scale,
-                           layout=N.LAYOUT_FEAT_MAJOR, window_f64=1)
+                           layout=N.LAYOUT_FEAT_MAJOR, window_f64=1, in_dtype=in_dtype)
         win = melbank.periodic_hann(nperseg)      # float64, multiplied in float64 like librosa does
         return N.Plan(spec, win, device=dev)
 
@@ -49,10 +49,12 @@ def log_specgram_batch(audio: torch.Tensor, window_size: int = 10, step_size: in
                        resampling_rate: int = RESAMPLING_RATE, div255: bool = False,
                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """(B, n) slices -> (B, 256, 1 + (n-1)//hop) log power spectrograms (frequency-major), one launch.
-    div255=True folds the ToTorchFormatTensor division in, giving what the encoder consumes."""
-    x, origin = to_device_rows(audio)
+    div255=True folds the ToTorchFormatTensor division in, giving what the encoder consumes.
+    int16 input is the pcm_s16le audio the reference extracts (recognition/dataset/extract_audio.py:9), decoded in
+    the kernel as s / 32768 like librosa.load does (epic_kitchen.py:135)."""
+    x, origin = to_device_rows(audio, pcm_ok=True)
     nperseg, hop = _params(window_size, step_size, resampling_rate)
-    plan = _logspec_plan(x.device.index, nperseg, hop, eps, 1.0 / 255.0 if div255 else 1.0)
+    plan = _logspec_plan(x.device.index, nperseg, hop, eps, 1.0 / 255.0 if div255 else 1.0, IN_CODES[x.dtype])
     y = run_rows(plan, x, out)
     return y if origin.type == "cuda" else y.to(origin)
 
@@ -62,7 +64,10 @@ def log_specgram(audio, window_size: int = 10, step_size: int = 5, eps: float = 
     """_log_specgram(self, audio, window_size=10, step_size=5, eps=1e-6): (n,) -> (256, frames).
     numpy in -> numpy out, tensor in -> tensor out (on the tensor's device)."""
     is_np = isinstance(audio, np.ndarray)
-    t = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float32)) if is_np else audio
+    if is_np:
+        t = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.int16 if audio.dtype == np.int16 else np.float32))
+    else:
+        t = audio
     if t.dim() != 1:
         raise ValueError(f"expected a 1-D audio slice, got {tuple(t.shape)}")
     y = log_specgram_batch(t[None, :], window_size, step_size, eps, resampling_rate)[0]
@@ -99,15 +104,18 @@ def extract_sound_features(recordings: Sequence[torch.Tensor], rec_index: Sequen
     recordings[rec_index[i]] around (start_frame[i] + idx[i]) / fps_spec[i] is transformed straight from
     the packed device-resident recordings (no per-slice copy).  All slices of one call must have the same
     length (interior slices are 30 672 samples, edge slices 30 696: call once per length).
+    Recordings that are all int16 stay 16-bit PCM on the device (half the memory) and are decoded in the kernel.
     Returns (B, 1, 256, frames)."""
     require_gpu()
     dev = torch.device("cuda", torch.cuda.current_device())
-    recs = [r.to(device=dev, dtype=torch.float32).reshape(-1) for r in recordings]
+    pcm = len(recordings) > 0 and all(r.dtype == torch.int16 for r in recordings)
+    el = torch.int16 if pcm else torch.float32
+    recs = [r.to(device=dev, dtype=el).reshape(-1) for r in recordings]
     lengths = [int(r.numel()) for r in recs]
     starts = np.zeros(len(recs), dtype=np.int64)
     if recs:
         starts[1:] = np.cumsum(lengths[:-1])
-    packed = torch.cat(recs) if recs else torch.empty(0, device=dev)
+    packed = torch.cat(recs) if recs else torch.empty(0, dtype=el, device=dev)
     bounds = [sound_slice_bounds(start_frame[i], idx[i], fps_spec[i], lengths[rec_index[i]], resampling_rate)
               for i in range(len(rec_index))]
     sizes = {r - l for l, r in bounds}
@@ -115,7 +123,7 @@ def extract_sound_features(recordings: Sequence[torch.Tensor], rec_index: Sequen
         raise ValueError(f"slices of different lengths in one call: {sorted(sizes)}")
     n = sizes.pop()
     nperseg, hop = _params(10, 5, resampling_rate)
-    plan = _logspec_plan(dev.index, nperseg, hop, 1e-6, 1.0 / 255.0 if div255 else 1.0)
+    plan = _logspec_plan(dev.index, nperseg, hop, 1e-6, 1.0 / 255.0 if div255 else 1.0, IN_CODES[el])
     frames, feat = plan.out_shape(n)
     out = torch.empty((len(bounds), 1, feat, frames), dtype=torch.float32, device=dev)
     if len(bounds) == 0 or frames == 0:

@@ -13,7 +13,7 @@ import torch
 
 from . import _native as N
 from . import melbank
-from .plans import OUT_CODES, cached_plan, run_rows, to_device_rows
+from .plans import IN_CODES, OUT_CODES, cached_plan, run_rows, to_device_rows
 
 _EPS = float(torch.finfo(torch.float32).eps)
 
@@ -26,11 +26,11 @@ def _fbank_plan(device: int, *, sample_frequency: float, frame_length: float, fr
                 window_type: str, blackman_coeff: float, preemphasis_coefficient: float, remove_dc_offset: bool,
                 round_to_power_of_two: bool, low_freq: float, high_freq: float, use_log_fbank: bool,
                 out_frames: int = 0, pad_value: float = 0.0, out_shift: float = 0.0, out_scale: float = 1.0,
-                out_dtype: int = N.OUT_F32) -> N.Plan:
+                out_dtype: int = N.OUT_F32, in_dtype: int = N.IN_F32) -> N.Plan:
     key = ("fbank", float(sample_frequency), float(frame_length), float(frame_shift), int(num_mel_bins), window_type,
            float(blackman_coeff), float(preemphasis_coefficient), bool(remove_dc_offset), bool(round_to_power_of_two),
            float(low_freq), float(high_freq), bool(use_log_fbank), int(out_frames), float(pad_value), float(out_shift),
-           float(out_scale), int(out_dtype))
+           float(out_scale), int(out_dtype), int(in_dtype))
 
     def build(dev: int) -> N.Plan:
         shift = int(sample_frequency * frame_shift * 0.001)
@@ -50,7 +50,7 @@ def _fbank_plan(device: int, *, sample_frequency: float, frame_length: float, fr
                            preemph=float(preemphasis_coefficient), power=2,
                            log_kind=N.LOG_LN_MAX if use_log_fbank else N.LOG_NONE, log_floor=_EPS,
                            out_shift=out_shift, out_scale=out_scale, out_frames=out_frames, pad_value=pad_value,
-                           layout=N.LAYOUT_TIME_MAJOR, out_dtype=out_dtype)
+                           layout=N.LAYOUT_TIME_MAJOR, out_dtype=out_dtype, in_dtype=in_dtype)
         win = melbank.kaldi_window(window_type, size, blackman_coeff)
         return N.Plan(spec, win, bs, bl, bw, device=dev)
 
@@ -81,16 +81,19 @@ def fbank_batch(waveforms: torch.Tensor, *, out_frames: int = 0, pad_value: floa
     """Batched form: (B, n) -> (B, m, num_mel_bins), one launch for the whole batch.  With out_frames > 0
     each clip is cut / padded (pad_value) to out_frames frames and (x + out_shift) * out_scale is applied.
     dtype=torch.float16 / torch.bfloat16 stores the float32 result rounded to nearest even (what a consumer
-    under autocast would cast it to); only the power-of-two 512-point path implements it."""
+    under autocast would cast it to); only the power-of-two 512-point path implements it.
+    An int16 tensor is taken as 16-bit PCM (value s / 32768, what torchaudio.load makes of the reference's FLAC
+    files, vggsound.py:66) and decoded inside the kernel: same bits out as for the decoded float32 waveform."""
     if dtype not in OUT_CODES:
         raise ValueError("dtype must be torch.float32, torch.float16 or torch.bfloat16")
-    x, origin = to_device_rows(waveforms)
+    x, origin = to_device_rows(waveforms, pcm_ok=True)
     plan = _fbank_plan(x.device.index, sample_frequency=sample_frequency, frame_length=frame_length,
                        frame_shift=frame_shift, num_mel_bins=num_mel_bins, window_type=window_type,
                        blackman_coeff=blackman_coeff, preemphasis_coefficient=preemphasis_coefficient,
                        remove_dc_offset=remove_dc_offset, round_to_power_of_two=round_to_power_of_two,
                        low_freq=low_freq, high_freq=high_freq, use_log_fbank=use_log_fbank, out_frames=out_frames,
-                       pad_value=pad_value, out_shift=out_shift, out_scale=out_scale, out_dtype=OUT_CODES[dtype])
+                       pad_value=pad_value, out_shift=out_shift, out_scale=out_scale, out_dtype=OUT_CODES[dtype],
+                       in_dtype=IN_CODES[x.dtype])
     y = run_rows(plan, x, out)
     return y if origin.type == "cuda" else y.to(origin)
 

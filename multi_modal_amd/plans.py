@@ -15,6 +15,8 @@ from . import _native as N
 
 OUT_DTYPES = {N.OUT_F32: torch.float32, N.OUT_F16: torch.float16, N.OUT_BF16: torch.bfloat16}
 OUT_CODES = {v: k for k, v in OUT_DTYPES.items()}
+IN_DTYPES = {N.IN_F32: torch.float32, N.IN_S16: torch.int16}
+IN_CODES = {v: k for k, v in IN_DTYPES.items()}
 
 _plans: Dict[Hashable, N.Plan] = {}
 _plans_lock = threading.Lock()
@@ -49,13 +51,16 @@ def clear_plans() -> None:
         _plans.clear()
 
 
-def to_device_rows(x: torch.Tensor) -> Tuple[torch.Tensor, torch.device]:
-    """(rows, n) float32 tensor with unit inner stride on a GPU, plus the device the caller's data was on."""
+def to_device_rows(x: torch.Tensor, pcm_ok: bool = False) -> Tuple[torch.Tensor, torch.device]:
+    """(rows, n) float32 tensor with unit inner stride on a GPU, plus the device the caller's data was on.
+    With pcm_ok an int16 tensor stays int16 (16-bit PCM, decoded inside the kernel as s / 32768)."""
     require_gpu()
     origin = x.device
     if x.dim() != 2:
         raise ValueError(f"expected a 2-D (rows, samples) tensor, got {tuple(x.shape)}")
-    if x.dtype != torch.float32:
+    if x.dtype == torch.int16 and not pcm_ok:
+        raise TypeError("this transform takes float samples; int16 PCM is read by the log-mel and log-spectrogram transforms only")
+    if x.dtype != torch.float32 and x.dtype != torch.int16:
         x = x.to(torch.float32)
     if not x.is_cuda:
         x = x.cuda(non_blocking=False)
@@ -69,7 +74,7 @@ def to_device_rows(x: torch.Tensor) -> Tuple[torch.Tensor, torch.device]:
 def run_rows(plan: N.Plan, x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
     """Run `plan` over the rows of a CUDA tensor (rows, n).  Returns (rows, frames, feat) for time-major
     plans and (rows, feat, frames) for feature-major ones.  Asynchronous on the current stream."""
-    assert x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
+    assert x.is_cuda and x.dim() == 2 and x.dtype == IN_DTYPES[plan.spec.in_dtype]
     rows, n = x.shape
     frames, feat = plan.out_shape(n)
     shape = (rows, frames, feat) if plan.spec.layout == N.LAYOUT_TIME_MAJOR or plan.spec.kind == N.KIND_FRAME \

@@ -18,6 +18,8 @@ def frame_signal(signal: torch.Tensor, frame_length: int, hop_length: int, windo
         raise ValueError('Wrong `window` length: expected {}, got {}'.format(window.shape[0], frame_length))
     lead = tuple(signal.shape[:-1])
     rows = signal.reshape(-1, signal.shape[-1])
+    if rows.dtype == torch.int16:
+        rows = rows.to(torch.float32)      # framing moves values, it does not decode them: exact in float32
     x, origin = to_device_rows(rows)
     spec = N.make_spec(kind=N.KIND_FRAME, win_len=int(frame_length), hop=int(hop_length), frames_mode=N.FRAMES_CEIL)
     plan = N.Plan(spec, window.detach().to("cpu", torch.float32).numpy(), device=x.device.index)   # window is data: no cache

@@ -2,7 +2,7 @@
 """Throughput of the secondary configurations (BASELINE.json configs[2], the EPIC parity configuration and
 configs[4] per GPU) on one GPU: units/s, achieved algorithmic GB/s and fraction of the 8 TB/s HBM peak.
 
-    python scripts/bench_configs.py [har] [epic] [logmel] [--iters 20]
+    python scripts/bench_configs.py [har] [epic] [logmel] [pcm] [--iters 20]
 
 bench.py imports `run_config` to append the same lines to its JSON under "secondary".
 """
@@ -58,12 +58,20 @@ def run_config(name: str, dev: torch.device, iters: int = 20) -> dict:
         avg, mn = timeit(lambda: mm.logmel.log_mel_spectrogram(x, out=out), iters)
         return _line("long-utterance log-mel (1024, 480000) -> (1024, 80, 3000), n_fft 400, kernel " + mm.plans.last_kernel(),
                      "utterances/s", B, 480000 * 4 + 80 * 3000 * 4, avg, mn)
+    if name == "pcm":
+        B = 4096
+        x = (0.1 * torch.randn(B, 160000, device=dev, generator=g)).clamp_(-1, 1).mul_(32767.0).round_().to(torch.int16)
+        out = torch.empty(B, 384, 128, device=dev)
+        avg, mn = timeit(lambda: mm.preprocessing_audio_batch(x, out=out), iters)
+        return _line("VGGSound log-mel from 16-bit PCM (4096, 160000) int16 -> (4096, 384, 128), kernel " + mm.plans.last_kernel(),
+                     "clips/s", B, 153600 * 2 + 384 * 128 * 4, avg, mn)
     raise ValueError(name)
 
 
 def main():
     iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 20
-    which = [a for a in sys.argv[1:] if a in ("har", "epic", "logmel")] or ["har", "epic", "logmel"]
+    names = ("har", "epic", "logmel", "pcm")
+    which = [a for a in sys.argv[1:] if a in names] or list(names)
     dev = torch.device("cuda", 0)
     for name in which:
         print(json.dumps(run_config(name, dev, iters)), flush=True)

@@ -7,7 +7,7 @@ Not part of the test suite (it takes a minute or two); it is the wide net behind
 tests/test_gpu_parity.py.  Every case prints one line; the script exits non-zero on the first case outside its
 tolerance.  Tolerances are those of the fixed tests: kaldi log-mel p99.9 <= 1e-4 and max <= 2e-3, log-mel
 (n_fft 400) max <= 1e-4, EPIC log spectrogram max <= 1e-4, HAR magnitudes max <= 1e-6, frame_signal exact,
-16-bit output equal to the rounded float32 output.
+16-bit output equal to the rounded float32 output, 16-bit PCM input equal to the decoded float32 input.
 """
 import os
 import sys
@@ -91,6 +91,26 @@ def case_half(rng):
     return f"half {dtype} b={b} n={n}", mx, mx, ok
 
 
+def case_pcm(rng):
+    """16-bit PCM input against the decoded float32 waveform: bit-equal through the n_fft 512 kernel (any alignment),
+    oracle tolerance through the any-length kernel."""
+    n = int(rng.integers(400, 100000))
+    b = int(rng.integers(1, 5))
+    off = int(rng.integers(0, 4))
+    s16 = torch.from_numpy(rng.integers(-32768, 32768, size=(b, n + 4), dtype=np.int16)).cuda()
+    f32 = s16.to(torch.float32) / 32768.0
+    if rng.integers(2):
+        got = mm.preprocessing_audio_batch(s16[:, off:off + n])
+        ref = mm.preprocessing_audio_batch(f32[:, off:off + n])
+        ok = bool(torch.equal(got, ref))
+        mx = float((got - ref).abs().max())
+        return f"pcm fbank512 b={b} n={n} off={off}", mx, mx, ok
+    got = mm.log_specgram_batch(s16[:, off:off + n]).cpu().numpy()
+    ref = np.stack([O.log_specgram(r) for r in f32[:, off:off + n].cpu().numpy()])
+    mx, p = stats(got - ref)
+    return f"pcm epic b={b} n={n} off={off}", mx, p, mx <= 1e-4
+
+
 def case_har(rng):
     t = int(rng.integers(32, 700))
     nov = int(rng.choice([28, 28, 24, 16, 0, 31, 30]))
@@ -120,7 +140,7 @@ def main():
     cases = int(sys.argv[sys.argv.index("--cases") + 1]) if "--cases" in sys.argv else 200
     seed = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 0
     rng = np.random.default_rng(seed)
-    makers = [case_fbank, case_fbank, case_logmel, case_logmel, case_har, case_frame, case_epic, case_half]
+    makers = [case_fbank, case_fbank, case_logmel, case_logmel, case_har, case_frame, case_epic, case_half, case_pcm]
     worst = {}
     for i in range(cases):
         fn = makers[i % len(makers)]

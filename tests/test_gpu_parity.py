@@ -573,3 +573,85 @@ def test_plans_shared_between_threads_and_streams(mm):
     assert not errs, errs
     for t in range(4):
         assert torch.equal(got[t][0], want[t][0]) and torch.equal(got[t][1], want[t][1])
+
+
+def _pcm(kind, n, seed):
+    """A synthetic waveform quantised the way a 16-bit FLAC / pcm_s16le file holds it."""
+    return np.clip(np.round(synth(kind, n, seed).astype(np.float64) * 32768.0), -32768, 32767).astype(np.int16)
+
+
+def test_vggsound_pcm_input(mm, O):
+    """16-bit PCM clips decoded inside the n_fft 512 kernel: bit for bit the features of the decoded float32
+    waveform (s / 32768), for the 4-byte-load variant, the odd-offset variant, ragged lengths and 16-bit output;
+    and the oracle's values on the decoded waveform."""
+    s = np.stack([_pcm(k, 160002, 300 + i) for i, k in enumerate(KINDS)])
+    f = s.astype(np.float32) / np.float32(32768.0)
+    d_s, d_f = torch.from_numpy(s).cuda(), torch.from_numpy(f).cuda()
+    got = mm.preprocessing_audio_batch(d_s[:, :160000].contiguous())
+    assert mm.plans.last_kernel() == "fbank512" and got.dtype == torch.float32
+    assert torch.equal(got, mm.preprocessing_audio_batch(d_f[:, :160000].contiguous()))
+    ref = np.stack([O.preprocessing_audio(torch.from_numpy(c[:160000])[None]).numpy() for c in f])
+    assert np.abs(got.cpu().numpy() - ref).max() <= 5e-4
+    # rows that start on an odd sample (2-byte aligned only) and an odd row stride: the 2-byte-load variant against
+    # the float variant that also loads sample by sample
+    assert torch.equal(mm.preprocessing_audio_batch(d_s[:, 1:160001]), mm.preprocessing_audio_batch(d_f[:, 1:160001]))
+    # even offset, even stride, but a view: 4-byte loads
+    assert torch.equal(mm.preprocessing_audio_batch(d_s[:, 2:160002]), mm.preprocessing_audio_batch(d_f[:, 2:160002]))
+    for n in (399, 400, 12345):
+        assert torch.equal(mm.preprocessing_audio_batch(d_s[:, :n].contiguous()), mm.preprocessing_audio_batch(d_f[:, :n].contiguous()))
+    assert torch.equal(mm.preprocessing_audio_batch(d_s[:, :160000].contiguous(), dtype=torch.float16), got.to(torch.float16))
+    # CPU int16 tensor in -> CPU float32 tensor out
+    one = mm.preprocessing_audio(torch.from_numpy(s[0:1, :160000]))
+    assert one.device.type == "cpu" and np.array_equal(one.numpy(), got[0].cpu().numpy())
+
+
+def test_fbank_pcm_other_parameters(mm, O):
+    """PCM input through other log-mel parameter sets: a 512-point plan without DC removal / pre-emphasis, an odd
+    window (2-byte loads), and windows served by the any-length kernel (n_fft 256 and 400)."""
+    s = torch.from_numpy(np.stack([_pcm("noise0.1", 48000, 31), _pcm("uniform", 48000, 32)])).cuda()
+    f = s.to(torch.float32) / 32768.0
+    cases = [(dict(sample_frequency=16000, num_mel_bins=40, remove_dc_offset=False, preemphasis_coefficient=0.0, window_type="rectangular"), "fbank512"),
+             (dict(sample_frequency=16000, num_mel_bins=23), "fbank512"),
+             (dict(sample_frequency=11025.0, num_mel_bins=64), "fbank512"),
+             (dict(sample_frequency=8000, num_mel_bins=40), "dftgen"),
+             (dict(sample_frequency=16000, num_mel_bins=80, round_to_power_of_two=False), "dftgen")]
+    for kw, kernel in cases:
+        got = mm.fbank_batch(s, **kw)
+        assert mm.plans.last_kernel() == kernel, (kw, mm.plans.last_kernel())
+        if kernel == "fbank512":
+            assert torch.equal(got, mm.fbank_batch(f, **kw)), kw
+        ref = O.kaldi_fbank(f[:1].cpu(), **kw).numpy()
+        mx, p999 = _stats(got[0].cpu().numpy() - ref)
+        assert p999 <= 1e-4 and mx <= 2e-3, (kw, mx, p999)
+
+
+def test_epic_pcm_input(mm, O):
+    """pcm_s16le recordings (what extract_audio.py writes) straight into the log-spectrogram kernel: the bits of the
+    decoded float32 path, per slice and through the packed-recordings entry point."""
+    s = _pcm("noise0.1", 30672, 8)
+    f = s.astype(np.float32) / np.float32(32768.0)
+    got = mm.log_specgram(s)
+    assert got.dtype == np.float32 and np.array_equal(got, mm.log_specgram(f))
+    assert np.abs(got - O.log_specgram(f)).max() <= 1e-4
+    recs = [_pcm("noise0.1", 24000 * 5, 1), _pcm("uniform", 24000 * 3 + 17, 2)]
+    args = ([0, 0, 1, 1, 0], [100, 130, 30, 60, 170], [3, 0, 7, 2, 1], [60.0, 60.0, 50.0, 50.0, 60.0])
+    a = mm.epic.extract_sound_features([torch.from_numpy(r) for r in recs], *args)
+    b = mm.epic.extract_sound_features([torch.from_numpy(r.astype(np.float32) / np.float32(32768.0)) for r in recs], *args)
+    assert a.shape == (5, 1, 256, 256) and torch.equal(a, b)
+
+
+def test_pcm_rejected_where_not_implemented(mm):
+    x = torch.zeros(2, 6, 192, dtype=torch.int16, device="cuda")
+    with pytest.raises(TypeError):
+        mm.stft_mag(x)
+    with pytest.raises(TypeError):
+        mm.logmel.log_mel_spectrogram(torch.zeros(1, 16000, dtype=torch.int16, device="cuda"))
+    from multi_modal_amd import _native as N
+    spec = N.make_spec(kind=N.KIND_STFT_MAG, n_fft=32, win_len=32, hop=4, frames_mode=N.FRAMES_SCIPY, pad_mode=N.PAD_ZERO,
+                       power=1, in_dtype=N.IN_S16)
+    with pytest.raises(mm.MmfeError, match="16-bit PCM"):
+        N.Plan(spec, np.ones(32, np.float32), device=0)
+    # framing moves values: int16 in, int16 out, exact
+    sig = torch.arange(-50, 50, dtype=torch.int16)
+    fr = mm.frame_signal(sig.cuda(), 16, 8)
+    assert fr.dtype == torch.int16 and fr.shape[-1] == 16

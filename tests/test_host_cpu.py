@@ -64,6 +64,15 @@ def test_bad_spec_rejected(N):
     spec = N.make_spec(kind=N.KIND_FBANK, n_fft=512, win_len=400, hop=400)
     spec.struct_size = 8
     assert N.load_library().mmfe_spec_out_shape(ctypes.byref(spec), 1000, ctypes.byref(fr), ctypes.byref(ft)) == -1
+    # input element type: float32 or 16-bit PCM, the latter for the log-mel / log-spectrogram kinds only
+    spec = N.make_spec(kind=N.KIND_FBANK, n_fft=512, win_len=400, hop=400, in_dtype=7)
+    assert N.load_library().mmfe_spec_out_shape(ctypes.byref(spec), 1000, ctypes.byref(fr), ctypes.byref(ft)) == -1
+    assert "in_dtype" in N.last_error()
+    spec = N.make_spec(kind=N.KIND_FRAME, win_len=16, hop=8, frames_mode=N.FRAMES_CEIL, in_dtype=N.IN_S16)
+    assert N.load_library().mmfe_spec_out_shape(ctypes.byref(spec), 1000, ctypes.byref(fr), ctypes.byref(ft)) == -1
+    assert "PCM" in N.last_error()
+    spec = N.make_spec(kind=N.KIND_FBANK, n_fft=512, win_len=400, hop=400, n_mel=128, in_dtype=N.IN_S16)
+    assert N.spec_out_shape(spec, 160000) == (400, 128)
 
 
 def test_shape_rules_match_the_oracle(N):
