@@ -20,6 +20,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <string>
 
 namespace mmfe {
 
@@ -269,6 +271,176 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Matrix-pipe form of the same transform for plain spectrograms (no mel bank, no DC removal / pre-emphasis, no
+// per-row clamp) with at most 120 mirrored tap pairs: EPIC's n_fft 511 / 240-tap configuration.
+//
+// About the window centre the spectrum of a block of frames is two real matrix products,
+//     Re[k][f] = sum_i cos(2 pi k m_i / N) * e[i][f],     Im[k][f] = sum_i -sin(2 pi k m_i / N) * o[i][f],
+// (bins x pairs) x (pairs x frames), and v_mfma_f64_16x16x4_f64 runs them at the float64 FMA rate of the vector
+// pipe without that pipe's per-FMA operand traffic: a wave owns 16 frames, keeps their folded taps e / o in
+// registers as the B operands (lane l: pair 4s + (l >> 4) of frame l & 15 for k-step s), walks the 16-bin tiles
+// of the spectrum and fetches the A operands (one cos / -sin pair per lane and step, bin 16*tile + (l & 15),
+// pair 4s + (l >> 4)) from the half-step twiddle table in LDS with an incrementally updated index.  The
+// accumulators hold bins 16*tile + (l >> 4) + 4j, j = 0..3, of frame l & 15: rounded to complex64, |.|^2, log,
+// affine and stored from registers.  Waves are independent (no LDS staging of samples, no barriers after the
+// table load): each lane reads its 2*KS samples straight from global memory (the 16 overlapping frames of a
+// tile live in L1/L2) and multiplies by the float64 window.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <typename S, int KS /* k-steps of 4 pairs */>
+__global__ void __launch_bounds__(kThreads, 2) dftmm_kernel(const DftArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double2* s_tw = reinterpret_cast<double2*>(smem);                     // 2*n_fft half-step twiddles (cos, -sin)
+    double* s_win = reinterpret_cast<double*>(s_tw + 2 * p.n_fft);        // win_len
+    for (int i = threadIdx.x; i < 2 * p.n_fft; i += kThreads) s_tw[i] = p.tw[i];
+    for (int i = threadIdx.x; i < p.win_len; i += kThreads) s_win[i] = p.window[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef MMFE_DFTMM_CLOCK
+    unsigned long long clk0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk0)::"memory");
+#endif
+    const int f = lane & 15, c = lane >> 4;
+    const int L = p.win_len;
+    const int H = (L + 1) >> 1;
+    const int odd = L & 1;
+    const int hi0 = L >> 1, lo0 = (L - 1) >> 1;
+    const int two_n = 2 * p.n_fft;
+    const unsigned tw_span = (unsigned)two_n * 16u;
+    const int n_tiles = (p.n_bins + 15) >> 4;
+    const int tiles_per_row = (p.frames_valid + 15) >> 4;
+    const int64_t n_items = (int64_t)p.n_rows * tiles_per_row;
+
+    for (int64_t item = (int64_t)blockIdx.x * (kThreads / 64) + wv; item < n_items; item += (int64_t)gridDim.x * (kThreads / 64)) {
+        const int row = (int)(item / tiles_per_row);
+        const int t0 = (int)(item - (int64_t)row * tiles_per_row) * 16;
+        const S* rp = row_ptr_as<S>(p.src, row);
+        const int base = (t0 + f) * p.hop + p.centre_shift;
+        const int first = t0 * p.hop + p.centre_shift;
+        const bool interior = first >= 0 && first + 15 * p.hop + L <= p.n_samples;      // wave-uniform: no padding test needed
+
+        // folded, windowed taps of this lane's pairs (float64 window x float32 sample, like the vector form)
+        // (the pair index is made opaque per item: otherwise the tap offsets, masks and window values of all KS steps
+        // are hoisted out of the item loop and held in registers next to e / o)
+        int cq = c;
+        asm volatile("" : "+v"(cq));
+        // all 2*KS samples of the lane are requested before the first one is used: one memory round trip per item
+        float xh[KS], xl[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int i = 4 * s + cq;
+            const bool live = i < H;
+            const int jh = live ? hi0 + i : hi0, jl = live ? lo0 - i : hi0;
+            if (interior) {
+                xh[s] = sample_value(rp[base + jh]);
+                xl[s] = sample_value(rp[base + jl]);
+            } else {
+                xh[s] = fetch_sample(rp, base + jh, p.n_samples, p.pad_mode);
+                xl[s] = fetch_sample(rp, base + jl, p.n_samples, p.pad_mode);
+            }
+        }
+        double e[KS], o[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int i = 4 * s + cq;
+            const bool live = i < H;
+            const int jh = live ? hi0 + i : hi0, jl = live ? lo0 - i : hi0;
+            const double uh = (double)xh[s] * s_win[jh], ul = (double)xl[s] * s_win[jl];
+            const bool self = odd && i == 0;          // the centre tap of an odd window pairs with itself
+            e[s] = live ? (self ? uh : uh + ul) : 0.0;
+            o[s] = (live && !self) ? uh - ul : 0.0;
+        }
+
+        const bool frame_ok = t0 + f < p.frames_valid;
+        // The A operands run R - 1 k-steps ahead of the MFMAs that use them, through a ring of R register pairs, and
+        // keep running across tile boundaries (the reads for the first steps of tile mt + 1 are issued under the
+        // last steps of tile mt), so neither the LDS latency nor its bank conflicts reach the matrix pipe.
+        constexpr int R = (KS % 6 == 0) ? 6 : 4;
+        static_assert(KS % R == 0, "ring slots must line up across tiles");
+        // byte offset into the twiddle table (LDS offset 0) of k * (2 m_i) mod 2N for bin k = 16*tile + (lane & 15) and
+        // pair i = 4s + c; one step of s advances 2 m_i by 8.  min(a, a - span) in unsigned arithmetic is the wrap-around.
+        auto cursor = [&](int mt, unsigned& at, unsigned& step) {
+            const int k = 16 * mt + f;
+            const int kk = k < p.n_bins ? k : 0;
+            at = (unsigned)((kk * (2 * c + 1 - odd)) % two_n) * 16u;
+            step = (unsigned)((8 * kk) % two_n) * 16u;
+        };
+        unsigned at, step;
+        cursor(0, at, step);
+        double2 ring[R];
+#pragma unroll
+        for (int s = 0; s < R - 1; ++s) {
+            ring[s] = *reinterpret_cast<const double2*>(smem + at);
+            at += step;
+            at = min(at, at - tw_span);
+        }
+        for (int mt = 0; mt < n_tiles; ++mt) {
+            unsigned at_n, step_n;
+            cursor(mt + 1 < n_tiles ? mt + 1 : mt, at_n, step_n);
+            f64x4 re = {0.0, 0.0, 0.0, 0.0}, im = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (s + R - 1 == KS) { at = at_n; step = step_n; }          // from here on the reads belong to the next tile
+                ring[(s + R - 1) % R] = *reinterpret_cast<const double2*>(smem + at);
+                at += step;
+                at = min(at, at - tw_span);
+                const double2 w = ring[s % R];
+                re = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, e[s], re, 0, 0, 0);
+                im = __builtin_amdgcn_mfma_f64_16x16x4f64(w.y, o[s], im, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);       // keeps the read-ahead distance as written
+            }
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // complex64 rounding of the (centre-referenced) spectrum, then fp32 |.|^2 like the reference's numpy expression
+                const float xr = (float)(re[j] * (double)p.spec_scale), xi = (float)(im[j] * (double)p.spec_scale);
+                v[j] = xr * xr + xi * xi;
+                if (p.power == 1) v[j] = sqrtf(v[j]);
+            }
+            apply_log_affine_block(v, p.la);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int bin = 16 * mt + c + 4 * j;
+                if (!frame_ok || bin >= p.n_bins) continue;
+                int64_t oi;
+                if (p.layout == MMFE_LAYOUT_FEAT_MAJOR) oi = ((int64_t)row * p.n_feat + bin) * p.out_frames + (t0 + f);
+                else oi = ((int64_t)row * p.out_frames + (t0 + f)) * p.n_feat + bin;
+                p.out[oi] = v[j];
+            }
+        }
+    }
+#ifdef MMFE_DFTMM_CLOCK
+    unsigned long long clk1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk1)::"memory");
+    if (blockIdx.x == 0 && threadIdx.x == 0) printf("dftmm block 0 wave 0: %llu shader-clock ticks\n", clk1 - clk0);
+#endif
+}
+
+template <typename S, int KS>
+int dftmm_launch_variant(const DftArgs& a, int64_t items, size_t lds, hipStream_t stream) {
+    int resident = 1, cus = 256;
+    int rc = kernel_prepare(reinterpret_cast<const void*>(&dftmm_kernel<S, KS>), kThreads, lds, &resident, &cus);
+    if (rc) return rc;
+    const int64_t blocks = (items + kThreads / 64 - 1) / (kThreads / 64);
+    const int grid = (int)std::min<int64_t>(blocks, (int64_t)cus * resident);
+    hipLaunchKernelGGL((dftmm_kernel<S, KS>), dim3(grid), dim3(kThreads), lds, stream, a);
+    MMFE_HIP_CHECK(hipGetLastError());
+    return MMFE_OK;
+}
+
+// Plans the matrix-pipe form serves (MMFE_DFT_FORM=valu keeps them on the vector form).
+bool dftmm_supports(const mmfe_spec& s) {
+    if (const char* f = std::getenv("MMFE_DFT_FORM")) {
+        if (std::string(f) == "valu") return false;
+    }
+    const int pairs = (s.win_len + 1) / 2;
+    const size_t lds = (size_t)s.n_fft * 32 + (size_t)s.win_len * 8;
+    return s.n_mel == 0 && !s.remove_dc && s.preemph == 0.f && !(s.clamp_below_max > 0.f) && pairs <= 120 && lds <= 64 * 1024;
+}
+
 // extremes[0..cap) = running maximum, extremes[cap..2cap) = running minimum, both in ordered-int form
 __global__ void rowmax_init_kernel(int* extremes, int n, int cap) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -387,6 +559,19 @@ int dftgen_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
         int rc = rowmax_init_launch(plan, n_rows, stream);
         if (rc) return rc;
         a.rowmax = plan.d_rowmax;
+    }
+    if (dftmm_supports(s)) {
+        const size_t mm_lds = (size_t)s.n_fft * 32 + (size_t)s.win_len * 8;
+        const int64_t items = n_rows * ((frames_valid + 15) / 16);
+        const int ksteps = ((s.win_len + 1) / 2 + 3) / 4;
+        const bool pcm16 = s.in_dtype == MMFE_IN_S16;
+#define MMFE_DFTMM_DISPATCH(KS_)                                                                     \
+        if (ksteps <= KS_) return pcm16 ? dftmm_launch_variant<int16_t, KS_>(a, items, mm_lds, stream)  \
+                                        : dftmm_launch_variant<float, KS_>(a, items, mm_lds, stream);
+        MMFE_DFTMM_DISPATCH(8)
+        MMFE_DFTMM_DISPATCH(16)
+        MMFE_DFTMM_DISPATCH(30)
+#undef MMFE_DFTMM_DISPATCH
     }
     const size_t p_bytes = (size_t)FR * (plan.n_bins + 1) * 4;
     a.p_alias = (plan.n_bins <= 256 && p_bytes <= (size_t)s.win_len * FR * 8) ? 1 : 0;

@@ -24,3 +24,5 @@ run pmc_sq2 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIV
 run pmc_fetch --kernel-trace --pmc FETCH_SIZE || exit 1
 run pmc_write --kernel-trace --pmc WRITE_SIZE || exit 1
 run pmc_grbm --kernel-trace --pmc GRBM_GUI_ACTIVE GRBM_COUNT || exit 1
+# matrix-pipe occupancy (the EPIC kernel's float64 MFMA form); a pass of its own, not fatal if a counter is missing
+run pmc_mfma --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA || true

@@ -655,3 +655,51 @@ def test_pcm_rejected_where_not_implemented(mm):
     sig = torch.arange(-50, 50, dtype=torch.int16)
     fr = mm.frame_signal(sig.cuda(), 16, 8)
     assert fr.dtype == torch.int16 and fr.shape[-1] == 16
+
+
+@pytest.mark.parametrize("n_fft,win,hop,pad", [(511, 240, 120, "constant"), (511, 239, 120, "constant"), (256, 120, 50, "reflect"),
+                                              (64, 48, 16, "constant"), (400, 33, 7, "reflect"), (1024, 200, 100, "constant"),
+                                              (2048, 200, 100, "constant")])
+def test_plain_spectrogram_matrix_form(mm, O, n_fft, win, hop, pad):
+    """Plain spectrograms with up to 120 mirrored tap pairs take the float64 matrix-pipe form of the any-length DFT
+    kernel (even and odd windows, 8 / 16 / 30 k-step variants, both layouts, |X| and |X|^2, PCM input, ragged frame
+    tiles); checked against the oracle's centred STFT and against the vector form of the same kernel."""
+    import os
+    from multi_modal_amd import _native as N, melbank, plans
+    x = np.stack([synth("noise0.1", 5000, 11), synth("sine+noise", 5000, 12)])
+    stft = [O.centred_stft(r, n_fft, hop, win, pad_mode=pad) for r in x]
+    for layout, power, log_kind in [(N.LAYOUT_FEAT_MAJOR, 2, N.LOG_LN_ADD), (N.LAYOUT_TIME_MAJOR, 1, N.LOG_NONE)]:
+        spec = N.make_spec(kind=N.KIND_LOGSPEC, n_fft=n_fft, win_len=win, win_off=(n_fft - win) // 2, hop=hop,
+                           pad_mode=N.PAD_ZERO if pad == "constant" else N.PAD_REFLECT, frames_mode=N.FRAMES_CENTER, power=power,
+                           log_kind=log_kind, log_floor=1e-6, layout=layout, window_f64=1)
+        plan = N.Plan(spec, melbank.periodic_hann(win), device=0)
+        assert plan.kernel == "dftgen"
+        got = plans.run_rows(plan, torch.from_numpy(x).cuda()).cpu().numpy()
+        os.environ["MMFE_DFT_FORM"] = "valu"
+        try:
+            alt = plans.run_rows(plan, torch.from_numpy(x).cuda()).cpu().numpy()
+        finally:
+            del os.environ["MMFE_DFT_FORM"]
+        plan.close()
+        if power == 2:
+            ref = np.stack([np.log(np.real(s * np.conj(s)) + np.float32(1e-6)) for s in stft])
+            tol = 1e-4
+        else:
+            ref = np.stack([np.abs(s).T for s in stft])
+            tol = 2e-6 * max(1.0, float(np.abs(ref).max()))
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= tol, (layout, np.abs(got - ref).max())
+        assert np.abs(got - alt).max() <= tol
+    # 16-bit PCM rows through the same form: bits of the decoded float path
+    s16 = torch.from_numpy(np.stack([_pcm("noise0.1", 5000, 13)])).cuda()
+    for in_dtype, rows in ((N.IN_S16, s16), (N.IN_F32, s16.to(torch.float32) / 32768.0)):
+        spec = N.make_spec(kind=N.KIND_LOGSPEC, n_fft=n_fft, win_len=win, win_off=(n_fft - win) // 2, hop=hop, pad_mode=N.PAD_ZERO,
+                           frames_mode=N.FRAMES_CENTER, power=2, log_kind=N.LOG_LN_ADD, log_floor=1e-6, layout=N.LAYOUT_FEAT_MAJOR,
+                           window_f64=1, in_dtype=in_dtype)
+        plan = N.Plan(spec, melbank.periodic_hann(win), device=0)
+        out = plans.run_rows(plan, rows).clone()
+        plan.close()
+        if in_dtype == N.IN_S16:
+            first = out
+        else:
+            assert torch.equal(first, out)
