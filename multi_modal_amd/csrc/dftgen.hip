@@ -10,10 +10,13 @@
 // an exact integer (no angle accumulation).  The same kernel serves centred log-mel with reflect
 // padding (n_fft = 400) and snip-edges fbank for window sizes the radix kernels do not cover.
 //
-// Mapping: a block owns FR consecutive frames of one row.  The windowed frames are staged once in
-// LDS as u[tap][frame]; thread k accumulates bin k of all FR frames in registers (one 8-byte
-// twiddle read and FR/4 broadcast 16-byte reads per tap), then the block applies |.|^2, the banded
-// mel projection (from LDS), the log and the affine map and stores in the requested layout.
+// Two forms.  Vector form (dftgen_kernel, every option): a block owns FR consecutive frames of one row; the windowed
+// frames are staged once in LDS as u[tap][frame] and folded about the window centre; each thread accumulates 4 bins
+// x 4 frames in float64 registers (4 broadcast reads of the folded taps and 4 twiddle reads per tap pair), then the
+// block applies |.|^2, the banded mel projection (from LDS), the log and the affine map and stores in the requested
+// layout.  Matrix-pipe form (dftmm_kernel, plain spectrograms with at most 120 tap pairs, which is the EPIC
+// configuration): the same folded DFT as two float64 MFMA products per 16 frames x 16 bins tile; see the comment
+// above that kernel.
 #include "mmfe_internal.h"
 #include "fft_regs.h"
 #include "log_affine.h"

@@ -49,8 +49,13 @@ def run_config(name: str, dev: torch.device, iters: int = 20) -> dict:
         x = (0.1 * torch.randn(B, 30672, device=dev, generator=g)).clamp_(-1, 1)
         out = torch.empty(B, 256, 256, device=dev)
         avg, mn = timeit(lambda: mm.log_specgram_batch(x, div255=True, out=out), iters)
-        return _line("EPIC (4096, 30672) -> (4096, 256, 256), n_fft 511, kernel dftgen (compute-bound)", "clips/s", B,
-                     30672 * 4 + 256 * 256 * 4, avg, mn)
+        line = _line("EPIC (4096, 30672) -> (4096, 256, 256), n_fft 511, kernel dftgen, float64 matrix-pipe form (compute-bound)",
+                     "clips/s", B, 30672 * 4 + 256 * 256 * 4, avg, mn)
+        # 256 frames x 256 bins x 120 mirrored tap pairs x 2 products x 2 flop per clip, against the 78.6 TFLOP/s float64 peak
+        flop = 256 * 256 * 120 * 2 * 2
+        line["TFLOP/s_f64"] = round(flop * line["value"] / 1e12, 1)
+        line["frac_of_78.6_TFLOPs"] = round(flop * line["value"] / 78.6e12, 4)
+        return line
     if name == "logmel":
         B = 1024
         x = (0.1 * torch.randn(B, 480000, device=dev, generator=g)).clamp_(-1, 1)
