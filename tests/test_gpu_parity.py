@@ -703,3 +703,33 @@ def test_plain_spectrogram_matrix_form(mm, O, n_fft, win, hop, pad):
             first = out
         else:
             assert torch.equal(first, out)
+
+
+def test_runs_are_capturable_in_a_hip_graph(mm):
+    """mmfe_run neither allocates nor synchronises, so a warmed-up call can be recorded into a HIP graph and replayed
+    on new data in the same buffers (all kernel families, including the two-pass clamp of the long-utterance log-mel)."""
+    g = torch.Generator(device="cuda").manual_seed(17)
+    cases = [
+        (lambda x, o: mm.preprocessing_audio_batch(x, out=o), (0.1 * torch.randn(8, 160000, device="cuda", generator=g)), (8, 384, 128)),
+        (lambda x, o: mm.stft_mag(x, out=o), torch.randn(64, 6, 192, device="cuda", generator=g), (64, 6, 17, 49)),
+        (lambda x, o: mm.log_specgram_batch(x, div255=True, out=o), (0.1 * torch.randn(4, 30672, device="cuda", generator=g)), (4, 256, 256)),
+        (lambda x, o: mm.logmel.log_mel_spectrogram(x, out=o), (0.1 * torch.randn(3, 48000, device="cuda", generator=g)), (3, 80, 300)),
+    ]
+    for fn, x, shape in cases:
+        out = torch.empty(shape, device="cuda")
+        fn(x, out)                                   # warm-up: plan creation and per-kernel launch attributes happen here
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                fn(x, out)
+        torch.cuda.current_stream().wait_stream(side)
+        x2 = torch.roll(x, shifts=7, dims=-1) * 0.5
+        want = fn(x2, torch.empty(shape, device="cuda")).clone()
+        x.copy_(x2)
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), shape
