@@ -111,6 +111,34 @@ def case_pcm(rng):
     return f"pcm epic b={b} n={n} off={off}", mx, p, mx <= 1e-4
 
 
+def case_logspec(rng):
+    """Plain centred log spectrograms with random DFT length / window / hop / padding: the float64 matrix-pipe form
+    (up to 120 mirrored tap pairs) or the vector form of the any-length kernel, against the oracle's centred STFT."""
+    from multi_modal_amd import _native as N, melbank, plans
+    n_fft = int(rng.integers(16, 1025))
+    win = int(rng.integers(2, min(n_fft, 300) + 1))
+    hop = int(rng.integers(1, 2 * win))
+    pad = str(rng.choice(["constant", "reflect"]))
+    n = int(rng.integers(n_fft // 2 + 2, 6000))
+    layout = int(rng.integers(2))
+    x = np.stack([synth(str(rng.choice(["noise0.1", "uniform", "sine+noise"])), n, int(rng.integers(1 << 30))) for _ in range(int(rng.integers(1, 4)))])
+    spec = N.make_spec(kind=N.KIND_LOGSPEC, n_fft=n_fft, win_len=win, win_off=(n_fft - win) // 2, hop=hop,
+                       pad_mode=N.PAD_ZERO if pad == "constant" else N.PAD_REFLECT, frames_mode=N.FRAMES_CENTER, power=2,
+                       log_kind=N.LOG_LN_ADD, log_floor=1e-6, layout=layout, window_f64=1)
+    plan = N.Plan(spec, melbank.periodic_hann(win), device=0)
+    got = plans.run_rows(plan, torch.from_numpy(x).cuda()).cpu().numpy()
+    plan.close()
+    ref = []
+    for r in x:
+        st = O.centred_stft(r, n_fft, hop, win, pad_mode=pad)
+        v = np.log(np.real(st * np.conj(st)) + np.float32(1e-6))
+        ref.append(v if layout == N.LAYOUT_FEAT_MAJOR else v.T)
+    ref = np.stack(ref)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    mx, p = stats(got - ref)
+    return f"logspec n_fft={n_fft} win={win} hop={hop} {pad} n={n} layout={layout}", mx, p, mx <= 1e-4
+
+
 def case_har(rng):
     t = int(rng.integers(32, 700))
     nov = int(rng.choice([28, 28, 24, 16, 0, 31, 30]))
@@ -140,7 +168,7 @@ def main():
     cases = int(sys.argv[sys.argv.index("--cases") + 1]) if "--cases" in sys.argv else 200
     seed = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 0
     rng = np.random.default_rng(seed)
-    makers = [case_fbank, case_fbank, case_logmel, case_logmel, case_har, case_frame, case_epic, case_half, case_pcm]
+    makers = [case_fbank, case_fbank, case_logmel, case_logmel, case_har, case_frame, case_epic, case_half, case_pcm, case_logspec, case_logspec]
     worst = {}
     for i in range(cases):
         fn = makers[i % len(makers)]
