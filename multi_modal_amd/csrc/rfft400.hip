@@ -148,7 +148,17 @@ __device__ __forceinline__ int stage_pos(int i) {
     else return i;
 }
 
-template <int HOP /* 160: specialised staging layout; 0: any hop <= 160 */, bool VEC /* 16-byte aligned row starts and hop % 4 == 0 */,
+// Four consecutive samples as floats: one 16-byte load of floats, or one 8-byte load of 16-bit PCM decoded as s / 32768.
+__device__ __forceinline__ float4 load4(const float* sp) { return *reinterpret_cast<const float4*>(sp); }
+__device__ __forceinline__ float4 load4(const int16_t* sp) {
+    const uint2 r = *reinterpret_cast<const uint2*>(sp);
+    constexpr float k = 1.0f / 32768.0f;
+    return make_float4((float)(int16_t)(r.x & 0xffffu) * k, (float)((int32_t)r.x >> 16) * k,
+                       (float)(int16_t)(r.y & 0xffffu) * k, (float)((int32_t)r.y >> 16) * k);
+}
+
+template <typename SMP /* input element: float or int16_t PCM */, int HOP /* 160: specialised staging layout; 0: any hop <= 160 */,
+          bool VEC /* row starts aligned to 4 samples and hop % 4 == 0 */,
           int S0, int S1, int S2, int S3 /* bins walked by the four mel instruction streams */, bool SPLIT /* last stream: runs split in two halves */>
 __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Args p) {
     constexpr int kSteps[kStreams] = {S0, S1, S2, S3};
@@ -207,16 +217,16 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
     // the samples under octet (r, o): lane holds pieces lane, lane+64, ... of 4 consecutive samples
     float4 pf[kPF];
     auto fetch = [&](unsigned r, unsigned o) {
-        const float* rp = row_ptr(p.src, r < (unsigned)p.n_rows ? r : 0);
+        const SMP* rp = row_ptr_as<SMP>(p.src, r < (unsigned)p.n_rows ? r : 0);
         const int first = (int)o * 8 * hop + p.shift;
         const bool interior = first >= 0 && first + span4 <= p.n_samples;     // wave-uniform
         if (interior) {
 #pragma unroll
             for (int q = 0; q < kPF; ++q) {
                 const int i = 4 * (lane + 64 * q);
-                const float* sp = rp + first + (i < span4 ? i : 0);
-                if (VEC) pf[q] = *reinterpret_cast<const float4*>(sp);
-                else pf[q] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                const SMP* sp = rp + first + (i < span4 ? i : 0);
+                if (VEC) pf[q] = load4(sp);
+                else pf[q] = make_float4(sample_value(sp[0]), sample_value(sp[1]), sample_value(sp[2]), sample_value(sp[3]));
             }
         } else {    // the octet touches an end of the row: padding rule per sample
 #pragma unroll
@@ -447,9 +457,9 @@ constexpr MelShape kShapes[] = {
     {{36, 32, 0, 0}, true},       // 40 bands
 };
 
-template <int HOP, bool VEC, int S0, int S1, int S2, int S3, bool SPLIT>
+template <typename SMP, int HOP, bool VEC, int S0, int S1, int S2, int S3, bool SPLIT>
 int launch_variant(const Rfft400Args& a, int64_t octets, hipStream_t stream) {
-    const void* fn = reinterpret_cast<const void*>(&rfft400_kernel<HOP, VEC, S0, S1, S2, S3, SPLIT>);
+    const void* fn = reinterpret_cast<const void*>(&rfft400_kernel<SMP, HOP, VEC, S0, S1, S2, S3, SPLIT>);
     const size_t lds = kTwBytes + (size_t)kWaves * kWaveBytes;
     int blocks_per_cu = 1, cus = 256;
     int rc = kernel_prepare(fn, 64 * kWaves, lds, &blocks_per_cu, &cus);
@@ -465,7 +475,7 @@ int launch_variant(const Rfft400Args& a, int64_t octets, hipStream_t stream) {
     const size_t n_st = (size_t)grid * kWaves * 8;
     MMFE_HIP_CHECK(hipMalloc((void**)&ta.stamps, n_st * 8));
     MMFE_HIP_CHECK(hipMemset(ta.stamps, 0, n_st * 8));
-    hipLaunchKernelGGL((rfft400_kernel<HOP, VEC, S0, S1, S2, S3, SPLIT>), dim3(grid), dim3(64 * kWaves), lds, stream, ta);
+    hipLaunchKernelGGL((rfft400_kernel<SMP, HOP, VEC, S0, S1, S2, S3, SPLIT>), dim3(grid), dim3(64 * kWaves), lds, stream, ta);
     MMFE_HIP_CHECK(hipDeviceSynchronize());
     std::vector<unsigned long long> h(n_st);
     MMFE_HIP_CHECK(hipMemcpy(h.data(), ta.stamps, n_st * 8, hipMemcpyDeviceToHost));
@@ -481,7 +491,7 @@ int launch_variant(const Rfft400Args& a, int64_t octets, hipStream_t stream) {
     }
     return MMFE_OK;
 #else
-    hipLaunchKernelGGL((rfft400_kernel<HOP, VEC, S0, S1, S2, S3, SPLIT>), dim3(grid), dim3(64 * kWaves), lds, stream, a);
+    hipLaunchKernelGGL((rfft400_kernel<SMP, HOP, VEC, S0, S1, S2, S3, SPLIT>), dim3(grid), dim3(64 * kWaves), lds, stream, a);
     MMFE_HIP_CHECK(hipGetLastError());
     return MMFE_OK;
 #endif
@@ -493,7 +503,7 @@ bool rfft400_supports(const mmfe_spec& s) {
     if (const char* f = std::getenv("MMFE_FORCE_GENERIC")) {
         if (std::string(f) == "1") return false;
     }
-    return s.in_dtype == MMFE_IN_F32 && s.n_fft == kN && s.n_mel > 0 && s.n_mel <= 128 && s.power == 2 && s.spec_scale == 1.0f && !s.window_f64 &&
+    return s.n_fft == kN && s.n_mel > 0 && s.n_mel <= 128 && s.power == 2 && s.spec_scale == 1.0f && !s.window_f64 &&
            !s.remove_dc && s.preemph == 0.f && s.hop >= 1 && s.hop <= kMaxHop && !(s.clamp_below_max > 0.f && !(s.out_scale > 0.f)) &&
            (s.frames_mode == MMFE_FRAMES_CENTER || s.frames_mode == MMFE_FRAMES_SNIP);
 }
@@ -633,15 +643,21 @@ int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64
         a.rowmax = reinterpret_cast<int*>(plan.d_rowmax);
         a.rowmin = a.rowmax + plan.rowmax_capacity;
     }
-    const bool vec = s.hop % 4 == 0 && a.shift % 4 == 0 && src.offsets == nullptr && src.stride % 4 == 0 && reinterpret_cast<uintptr_t>(src.base) % 16 == 0;
+    const bool pcm = s.in_dtype == MMFE_IN_S16;
+    const bool vec = s.hop % 4 == 0 && a.shift % 4 == 0 && src.offsets == nullptr && src.stride % 4 == 0 &&
+                     reinterpret_cast<uintptr_t>(src.base) % (pcm ? 8 : 16) == 0;
     int rc = MMFE_EINVAL;
     bool found = false;
 #define MMFE_R400_SHAPE(IDX, A, B, C, D, SP)                                                                     \
     if (plan.r400_shape == IDX) {                                                                                \
         found = true;                                                                                            \
-        if (s.hop == 160 && vec) rc = launch_variant<160, true, A, B, C, D, SP>(a, octets, stream);              \
-        else if (vec) rc = launch_variant<0, true, A, B, C, D, SP>(a, octets, stream);                           \
-        else rc = launch_variant<0, false, A, B, C, D, SP>(a, octets, stream);                                   \
+        if (pcm) {                                                                                               \
+            if (s.hop == 160 && vec) rc = launch_variant<int16_t, 160, true, A, B, C, D, SP>(a, octets, stream);     \
+            else if (vec) rc = launch_variant<int16_t, 0, true, A, B, C, D, SP>(a, octets, stream);                  \
+            else rc = launch_variant<int16_t, 0, false, A, B, C, D, SP>(a, octets, stream);                          \
+        } else if (s.hop == 160 && vec) rc = launch_variant<float, 160, true, A, B, C, D, SP>(a, octets, stream);    \
+        else if (vec) rc = launch_variant<float, 0, true, A, B, C, D, SP>(a, octets, stream);                        \
+        else rc = launch_variant<float, 0, false, A, B, C, D, SP>(a, octets, stream);                                \
     }
     MMFE_R400_SHAPE(0, 5, 19, 17, 0, true)
     MMFE_R400_SHAPE(1, 8, 20, 20, 0, true)

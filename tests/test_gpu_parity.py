@@ -640,12 +640,28 @@ def test_epic_pcm_input(mm, O):
     assert a.shape == (5, 1, 256, 256) and torch.equal(a, b)
 
 
+def test_logmel_pcm_input(mm):
+    """16-bit PCM utterances through the n_fft 400 radix kernel (8-byte loads, scalar loads at odd offsets, row-end
+    octets) and through the float64 any-length kernel: the bits of the decoded float32 path."""
+    s16 = torch.from_numpy(np.stack([_pcm("noise0.1", 48004, 41), _pcm("sine+noise", 48004, 42)])).cuda()
+    f32 = s16.to(torch.float32) / 32768.0
+    for off, n, hop in [(0, 48000, 160), (4, 48000, 160), (1, 47999, 160), (0, 20000, 100), (3, 5000, 37)]:
+        a = mm.logmel.log_mel_spectrogram(s16[:, off:off + n], hop_length=hop)
+        assert mm.plans.last_kernel() == "rfft400"
+        assert torch.equal(a, mm.logmel.log_mel_spectrogram(f32[:, off:off + n], hop_length=hop)), (off, n, hop)
+    a = mm.logmel.log_mel_spectrogram(s16[:, :16000], precision="float64")
+    assert mm.plans.last_kernel() == "dftgen"
+    assert torch.equal(a, mm.logmel.log_mel_spectrogram(f32[:, :16000], precision="float64"))
+    kw = dict(sample_frequency=16000, num_mel_bins=80, round_to_power_of_two=False, remove_dc_offset=False, preemphasis_coefficient=0.0)
+    b = mm.fbank_batch(s16[:, :48000].contiguous(), **kw)
+    assert mm.plans.last_kernel() == "rfft400"
+    assert torch.equal(b, mm.fbank_batch(f32[:, :48000].contiguous(), **kw))
+
+
 def test_pcm_rejected_where_not_implemented(mm):
     x = torch.zeros(2, 6, 192, dtype=torch.int16, device="cuda")
     with pytest.raises(TypeError):
         mm.stft_mag(x)
-    with pytest.raises(TypeError):
-        mm.logmel.log_mel_spectrogram(torch.zeros(1, 16000, dtype=torch.int16, device="cuda"))
     from multi_modal_amd import _native as N
     spec = N.make_spec(kind=N.KIND_STFT_MAG, n_fft=32, win_len=32, hop=4, frames_mode=N.FRAMES_SCIPY, pad_mode=N.PAD_ZERO,
                        power=1, in_dtype=N.IN_S16)
