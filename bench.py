@@ -184,7 +184,7 @@ def main():
         if gather is not None:
             res["allgather"] = gather
         if world == 1 and not args.no_secondary:
-            # the other BASELINE configurations that fit one GPU, a few launches each (not part of `value`)
+            # the other benchmark configurations that fit one GPU, a few launches each (not part of `value`)
             del x, out
             torch.cuda.empty_cache()
             try:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Throughput of the secondary configurations (BASELINE.json configs[2], the EPIC parity configuration and
-configs[4] per GPU) on one GPU: units/s, achieved algorithmic GB/s and fraction of the 8 TB/s HBM peak.
+"""Throughput of the secondary configurations (BASELINE.json configs[2], the EPIC parity configuration,
+configs[4] per GPU and the headline configuration fed with 16-bit PCM) on one GPU: units/s, achieved algorithmic GB/s and fraction of the 8 TB/s HBM peak.
 
     python scripts/bench_configs.py [har] [epic] [logmel] [pcm] [--iters 20]
 

@@ -462,7 +462,7 @@ def test_cal_norm(mm):
 
 
 def test_full_size_properties(mm):
-    """BASELINE configuration 2 at full size (4096 clips): properties that do not need the oracle.
+    """The headline benchmark configuration at full size (4096 VGGSound clips): properties that do not need the oracle.
     Every clip is one of 8 distinct waveforms, so equal clips must give bit-identical features wherever
     they sit in the batch, and the 8 distinct ones are checked against the small-batch result."""
     base = torch.from_numpy(np.stack([synth("noise0.1", 160000, 1234 + i) for i in range(8)])).cuda()
@@ -480,7 +480,7 @@ def test_full_size_properties(mm):
 
 
 def test_full_size_properties_har(mm):
-    """BASELINE configuration 3 at full size (262 144 windows x 6 axes): equal windows give bit-identical spectrograms
+    """The IMU benchmark configuration at full size (262 144 windows x 6 axes): equal windows give bit-identical spectrograms
     wherever they sit in the batch; scaling the input by a power of two scales the magnitudes exactly."""
     g = torch.Generator(device="cuda").manual_seed(4321)
     base = torch.randn(64, 6, 192, device="cuda", generator=g)
@@ -493,7 +493,7 @@ def test_full_size_properties_har(mm):
 
 
 def test_full_size_properties_logmel(mm):
-    """BASELINE configuration 5 per GPU (1024 utterances of 30 s): position independence of the radix kernel, and
+    """The long-utterance benchmark configuration per GPU (1024 utterances of 30 s): position independence of the radix kernel, and
     the clamp invariant of every utterance (no cell below max - 2 after the (x + 4) / 4 map)."""
     g = torch.Generator(device="cuda").manual_seed(99)
     base = (0.1 * torch.randn(8, 480000, device="cuda", generator=g)).clamp_(-1, 1)
