@@ -102,7 +102,7 @@ extern "C" {
 typedef struct mmfe_spec {
     int32_t struct_size;   /* = sizeof(mmfe_spec) */
     int32_t kind;          /* MMFE_KIND_* */
-    int32_t n_fft;         /* DFT length: any value in [2, 4096]; 512 and 400 have radix kernels, STFT_MAG needs 32 */
+    int32_t n_fft;         /* DFT length: any value in [2, 4096]; 512, 400 and (STFT_MAG) 32 have radix kernels */
     int32_t win_len;       /* number of window taps (<= n_fft); FRAME: frame_length */
     int32_t win_off;       /* position of tap 0 inside the n_fft-long DFT input (zeros elsewhere) */
     int32_t hop;

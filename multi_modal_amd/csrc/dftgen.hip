@@ -547,7 +547,9 @@ int dftgen_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
     a.frames_valid = (int)frames_valid;
     a.out_frames = (int)out_frames;
     a.n_fft = s.n_fft; a.win_len = s.win_len; a.win_off = s.win_off; a.hop = s.hop;
-    a.centre_shift = (s.frames_mode == MMFE_FRAMES_CENTER) ? s.win_off - s.n_fft / 2 : 0;
+    // frame t, tap j reads sample t*hop + j + centre_shift: librosa centres the n_fft-long frame on t*hop, scipy's zero
+    // boundary extension puts win_len/2 zeros in front of the row, snip-edges framing starts at the row's first sample
+    a.centre_shift = s.frames_mode == MMFE_FRAMES_CENTER ? s.win_off - s.n_fft / 2 : (s.frames_mode == MMFE_FRAMES_SCIPY ? -(s.win_len / 2) : 0);
     a.pad_mode = s.pad_mode;
     a.n_bins = plan.n_bins; a.n_mel = s.n_mel; a.n_feat = s.n_mel > 0 ? s.n_mel : plan.n_bins;
     a.remove_dc = s.remove_dc; a.preemph = s.preemph; a.power = s.power; a.spec_scale = s.spec_scale;

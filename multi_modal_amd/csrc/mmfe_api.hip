@@ -283,8 +283,19 @@ int mmfe_plan_create(const mmfe_spec* spec, const void* window, const int32_t* b
             }
             break;
         case MMFE_KIND_STFT_MAG:
-            p->impl = IMPL_STFT32;
-            rc = stft32_prepare(*p);
+            // nperseg 32 (the reference's IMU setting) has a kernel of its own; any other segment length runs on the
+            // any-length DFT kernel with scipy's framing
+            if (spec->n_fft == 32) {
+                p->impl = IMPL_STFT32;
+                rc = stft32_prepare(*p);
+            } else if (spec->frames_mode != MMFE_FRAMES_SCIPY || spec->pad_mode != MMFE_PAD_ZERO || spec->win_off != 0 ||
+                       spec->win_len != spec->n_fft || spec->n_mel != 0 || spec->out_frames != 0 || spec->clamp_below_max > 0.f) {
+                set_error("STFT_MAG: needs scipy framing with zero padding, win_len == n_fft, no mel bank, natural frame count");
+                rc = MMFE_EINVAL;
+            } else {
+                p->impl = IMPL_DFT_GENERIC;
+                rc = dftgen_prepare(*p);
+            }
             break;
         case MMFE_KIND_FRAME:
             if (spec->frames_mode != MMFE_FRAMES_CEIL) { set_error("FRAME: needs MMFE_FRAMES_CEIL"); rc = MMFE_EINVAL; break; }
@@ -323,7 +334,7 @@ int mmfe_run_slices(const mmfe_plan* plan, const void* recs, const int64_t* rec_
                     const int64_t* offsets, int64_t n_rows, int64_t n_samples, void* out, void* hip_stream) {
     if (rec_start == nullptr || rec_index == nullptr || offsets == nullptr) { set_error("NULL slice table"); return MMFE_EINVAL; }
     const Plan* p = reinterpret_cast<const Plan*>(plan);
-    if (p != nullptr && p->impl == IMPL_STFT32) { set_error("slices are not supported for STFT_MAG plans"); return MMFE_EINVAL; }
+    if (p != nullptr && p->impl == IMPL_STFT32) { set_error("slices are not supported by the 32-point STFT kernel"); return MMFE_EINVAL; }
     RowSource src{recs, 0, rec_start, rec_index, offsets};
     return run_common(p, src, n_rows, n_samples, out, hip_stream);
 }

@@ -749,3 +749,19 @@ def test_runs_are_capturable_in_a_hip_graph(mm):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, want), shape
+
+
+@pytest.mark.parametrize("nperseg,noverlap,t", [(16, 12, 100), (64, 48, 500), (100, 75, 1000), (33, 5, 400), (256, 128, 3000),
+                                               (300, 299, 700), (8, 0, 64)])
+def test_stft_mag_other_segment_lengths(mm, O, nperseg, noverlap, t):
+    """Segment lengths other than the reference's 32 run on the any-length DFT kernel with scipy's framing (matrix-pipe
+    form up to 240 taps, vector form beyond): against the oracle and against scipy itself."""
+    import scipy.signal
+    rng = np.random.default_rng(nperseg)
+    x = rng.standard_normal((3, 2, t)).astype(np.float32)
+    got = mm.stft_mag(torch.from_numpy(x).cuda(), nperseg=nperseg, noverlap=noverlap).cpu().numpy()
+    assert mm.plans.last_kernel() == "dftgen"
+    ref = O.stft_mag(x, nperseg=nperseg, noverlap=noverlap)
+    live = np.abs(scipy.signal.stft(x, fs=100, nperseg=nperseg, noverlap=noverlap)[-1])
+    assert got.shape == ref.shape == live.shape
+    assert np.abs(got - ref).max() <= 1e-6 and np.abs(got - live).max() <= 1e-6
