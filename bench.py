@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
-"""Front-end throughput benchmark: VGGSound 10 s 16 kHz clips -> (384, 128) normalised kaldi log-mel.
+"""Front-end throughput benchmark.
 
     python bench.py --gpus 1 --steps 100 --warmup 30
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--config vgg4096|vgg200k|logmel]
 
-A step is one pass of the fused front-end kernel over one device-resident batch of 4096 clips per GPU
-(BASELINE.json configs[1]); inputs are synthetic (0.1*N(0,1) clipped to +-1, seed 1234+rank) and already
-in HBM when the timed region starts.  Clips are independent, so ranks shard the batch with no data-path
-collective (weak scaling); the optional all-gather of features is timed separately.  Rank 0 prints ONE
-JSON line.  The warm-up / timed-iteration idiom mirrors classification/vggsound/latency.py:38-53.
+A step is one pass of the fused front-end over one device-resident batch per GPU; inputs are synthetic
+(0.1*N(0,1) clipped to +-1, seed 1234+rank) and already in HBM when the timed region starts.  Rows are
+independent, so ranks shard the batch with no data-path collective (weak scaling); the all-gather of features
+(RCCL over xGMI) is timed separately and reported under "allgather".  Rank 0 prints ONE JSON line.
+
+  --config vgg4096  (default) VGGSound 10 s 16 kHz clips -> (384, 128) normalised kaldi log-mel, 4096 clips per GPU:
+                    the configuration the headline metric is quoted on (BASELINE.json configs[1])
+  --config vgg200k  the same transform on 25 000 clips per GPU: with --gpus 8 the 200 000-clip set of configs[3],
+                    compute-only and compute + all-gather rates, gather GB/s against the 7 x 153 GB/s of xGMI
+  --config logmel   30 s utterances, n_fft 400 / hop 160 / 80 mel, 1024 utterances per GPU (configs[4])
+
+The warm-up / timed-iteration idiom mirrors classification/vggsound/latency.py:38-53.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,38 +35,113 @@ CLIP_SAMPLES = 160000
 OUT_FRAMES, N_MEL = 384, 128
 # algorithmic HBM bytes per clip: the 384 kept frames read 384*400 samples once, 384*128 floats are written
 BYTES_PER_CLIP = 384 * 400 * 4 + OUT_FRAMES * N_MEL * 4          # 811008
+UTT_SAMPLES, UTT_FRAMES, UTT_MEL = 480000, 3000, 80
+BYTES_PER_UTT = UTT_SAMPLES * 4 + UTT_MEL * UTT_FRAMES * 4       # 2880000
 HBM_PEAK_GBS = 8000.0                                             # MI355X HBM3E peak
+XGMI_PEAK_GBS = 7 * 153.0                                         # 7 point-to-point links per GPU
+
+CONFIGS = {
+    "vgg4096": dict(batch=4096, samples=CLIP_SAMPLES, out=(OUT_FRAMES, N_MEL), bytes_per_unit=BYTES_PER_CLIP, unit="clips/s",
+                    kernel="fbank512_kernel", metric="clips/sec (10 s 16 kHz -> log-mel) per node",
+                    workload="VGGSound 10 s 16 kHz mono clips -> kaldi 128-bin log-mel, cut to 384 frames, normalised "
+                             "(BASELINE configs[1])"),
+    "vgg200k": dict(batch=25000, samples=CLIP_SAMPLES, out=(OUT_FRAMES, N_MEL), bytes_per_unit=BYTES_PER_CLIP, unit="clips/s",
+                    kernel="fbank512_kernel", metric="clips/sec (10 s 16 kHz -> log-mel) per node",
+                    workload="VGGSound-size set, 25 000 clips per GPU (200 000 over 8 GPUs), same transform, features "
+                             "all-gathered over RCCL (BASELINE configs[3])"),
+    "logmel": dict(batch=1024, samples=UTT_SAMPLES, out=(UTT_MEL, UTT_FRAMES), bytes_per_unit=BYTES_PER_UTT, unit="utterances/s",
+                   kernel="rfft400_kernel (+ per-utterance clamp pass)", metric="utterances/sec (30 s 16 kHz -> 80-bin log-mel) per node",
+                   workload="30 s utterances, n_fft 400 / hop 160 / 80 Slaney mel bands, log10, per-utterance clamp "
+                            "(BASELINE configs[4])"),
+}
 
 
-def cpu_baseline(budget_s: float = 12.0, max_clips: int = 200000):
-    """The CPU restatement of the reference's per-clip front-end (oracle, kind 'port'), driven the way
-    the reference drives it: one clip per call, one thread (a DataLoader worker is one process)."""
+# ---- CPU baseline: the oracle driven the way the reference drives its front-end -----------------------------------
+def _cpu_loop(budget_s: float, max_clips: int = 10 ** 9):
+    """One worker: the per-clip CPU restatement (oracle.preprocessing_audio), one thread, for `budget_s` seconds."""
     from oracle import frontend_oracle as O
     torch.set_num_threads(1)
     g = torch.Generator().manual_seed(1234)
-    clips = (0.1 * torch.randn(32, 1, CLIP_SAMPLES, generator=g)).clamp_(-1, 1)
+    clips = (0.1 * torch.randn(8, 1, CLIP_SAMPLES, generator=g)).clamp_(-1, 1)
     O.preprocessing_audio(clips[0])          # warm-up
     n = 0
     t0 = time.perf_counter()
     while True:
-        O.preprocessing_audio(clips[n % 32])
+        O.preprocessing_audio(clips[n % 8])
         n += 1
         el = time.perf_counter() - t0
         if el >= budget_s or n >= max_clips:
             break
-    return {"value": round(n / el, 2), "unit": "clips/s", "cores": 1, "kind": "port",
-            "sample": f"{n} clips of {CLIP_SAMPLES} samples, one clip per call (oracle.preprocessing_audio), "
-                      f"{el:.1f} s on 1 of {os.cpu_count()} host cores"}
+    return n, el
 
 
-def load_traffic():
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/fbank_pmc_latest.json), or None."""
+def _cpu_workers(n_workers: int, budget_s: float):
+    """`n_workers` fresh single-threaded worker processes (the reference's DataLoader workers are processes,
+    classification/vggsound/dataset/vggsound.py:87), each looping for `budget_s` seconds after its own start-up.
+    Fresh processes, not forks: the parent has an initialised GPU context."""
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(budget_s)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for _ in range(n_workers)]
+    total, rate = 0, 0.0
+    for p in procs:
+        out = p.communicate(timeout=budget_s + 180)[0].decode()
+        n, el = out.strip().splitlines()[-1].split()
+        total += int(n)
+        rate += int(n) / float(el)
+    return total, rate
+
+
+def host_core_share() -> int:
+    """Cores this job may use: the box exports its share as OMP_NUM_THREADS (os.cpu_count() shows the whole machine)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, int(os.environ.get("OMP_NUM_THREADS", n)))
+    except ValueError:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(budget_s: float = 12.0, max_clips: int = 200000, legs=("1_thread", "4_workers", "all_cores")):
+    """The CPU restatement of the reference's per-clip front-end (oracle, kind 'port') timed three ways: one thread,
+    4 worker processes (how the reference runs it: DataLoader(num_workers=4), vggsound.py:87) and one worker per
+    available core.  `value` / `cores` at the top level are the 4-worker leg when it ran, else the single thread."""
+    per_leg = budget_s / max(1, len(legs))
+    res = {"unit": "clips/s", "kind": "port", "legs": {}}
+    if "1_thread" in legs:
+        n, el = _cpu_loop(per_leg, max_clips)
+        res["legs"]["1_thread"] = {"value": round(n / el, 2), "cores": 1, "clips": n, "seconds": round(el, 2)}
+    if "4_workers" in legs:
+        n, rate = _cpu_workers(4, per_leg)
+        res["legs"]["4_workers"] = {"value": round(rate, 2), "cores": 4, "clips": n, "seconds": round(per_leg, 2)}
+    if "all_cores" in legs:
+        c = host_core_share()
+        n, rate = _cpu_workers(c, per_leg)
+        res["legs"]["all_cores"] = {"value": round(rate, 2), "cores": c, "clips": n, "seconds": round(per_leg, 2)}
+    head = "4_workers" if "4_workers" in res["legs"] else next(iter(res["legs"]))
+    res["value"] = res["legs"][head]["value"]
+    res["cores"] = res["legs"][head]["cores"]
+    res["sample"] = (f"{res['legs'][head]['clips']} clips of {CLIP_SAMPLES} samples, one clip per call (oracle.preprocessing_audio), "
+                     f"{res['legs'][head]['seconds']} s on {res['cores']} single-threaded worker process(es); host shows "
+                     f"{os.cpu_count()} cores, share {host_core_share()}")
+    return res
+
+
+def load_traffic(kernel_avg_ms: float):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/fbank_pmc_latest.json).  Refused (None
+    plus the reason) when that profile is of another kernel or its average launch time is more than 10 % away from
+    this run's: the counters then describe a different build."""
     p = os.path.join(ROOT, "profiles", "fbank_pmc_latest.json")
     try:
         with open(p) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
-    except Exception:
-        return None
+            prof = json.load(f)
+    except Exception as exc:
+        return None, f"no profile: {exc!r}"
+    if "fbank512_kernel" not in prof.get("kernel_name", ""):
+        return None, "profile is of another kernel"
+    prof_ms = float(prof.get("avg_ns", 0.0)) * 1e-6
+    if prof_ms <= 0 or abs(prof_ms - kernel_avg_ms) > 0.10 * kernel_avg_ms:
+        return None, f"profile is stale: its kernel averaged {prof_ms:.4f} ms, this run {kernel_avg_ms:.4f} ms"
+    return prof.get("hbm_bytes_per_launch"), None
 
 
 def main():
@@ -66,14 +149,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--batch", type=int, default=4096, help="clips per GPU")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="vgg4096")
+    ap.add_argument("--batch", type=int, default=0, help="units per GPU (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true", help="multi-GPU: skip the separately timed all-gather of features")
     ap.add_argument("--no-secondary", action="store_true", help="skip the HAR / long-utterance / EPIC / 16-bit PCM configurations")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--precondition", type=float, default=0.5, help="seconds of untimed launches before the warm-up steps")
+    ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.cpu_worker > 0:            # a worker process of the CPU baseline: never touches the GPU
+        n, el = _cpu_loop(args.cpu_worker)
+        print(n, el, flush=True)
+        return
+
+    cfg = CONFIGS[args.config]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -89,13 +180,22 @@ def main():
     import multi_modal_amd as mm
     mm.load_library()
 
-    B = args.batch
+    B = args.batch if args.batch > 0 else cfg["batch"]
+    n = cfg["samples"]
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    x = (0.1 * torch.randn(B, CLIP_SAMPLES, device=dev, generator=g)).clamp_(-1, 1)
-    out = torch.empty(B, OUT_FRAMES, N_MEL, device=dev)
+    x = torch.empty(B, n, device=dev)
+    slab = max(1, (1 << 30) // n)                   # generated on the device in 4 GB slabs
+    for lo in range(0, B, slab):
+        hi = min(B, lo + slab)
+        x[lo:hi] = (0.1 * torch.randn(hi - lo, n, device=dev, generator=g)).clamp_(-1, 1)
+    out = torch.empty((B,) + cfg["out"], device=dev)
 
-    def step():
-        mm.preprocessing_audio_batch(x, out=out)
+    if args.config == "logmel":
+        def step():
+            mm.logmel.log_mel_spectrogram(x, out=out)
+    else:
+        def step():
+            mm.preprocessing_audio_batch(x, out=out)
 
     def fence():
         torch.cuda.synchronize()
@@ -103,11 +203,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # device pre-conditioning (not part of the W warm-up steps): a step lasts well under a millisecond, so a
+    # device pre-conditioning (not part of the W warm-up steps): a step lasts about a millisecond, so a
     # handful of warm-up steps ends before the GPU has left its idle clock state; keep it busy for ~0.5 s first
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < args.precondition:
-        for _ in range(50):
+        for _ in range(20):
             step()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -130,11 +230,11 @@ def main():
     kernel_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, ends))
     kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
 
-    # ---- optional: all-gather of features (multi-GPU only), timed separately -------------------------
+    # ---- the all-gather of features (RCCL), timed separately: compute + gather, and the gather alone ------------
     gather = None
     if use_dist and not args.no_allgather:
         try:
-            full = torch.empty(world * B, OUT_FRAMES, N_MEL, device=dev)
+            full = torch.empty((world * B,) + cfg["out"], device=dev)
             for _ in range(2):
                 dist.all_gather_into_tensor(full, out)
             fence()
@@ -145,23 +245,33 @@ def main():
                 dist.all_gather_into_tensor(full, out)
             fence()
             el = time.perf_counter() - t0
-            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            t0 = time.perf_counter()
+            for _ in range(k):
+                dist.all_gather_into_tensor(full, out)
+            fence()
+            el_g = time.perf_counter() - t0
+            t = torch.tensor([el, el_g], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
+            el, el_g = (float(v) for v in t.tolist())
             recv = (world - 1) * out.numel() * 4
-            gather = {"clips_per_s_with_allgather": round(world * B * k / el, 1), "ms_per_step": round(1e3 * el / k, 3),
-                      "received_bytes_per_rank": recv, "gathered_GB_per_s_per_rank": round(recv * k / el / 1e9, 1), "steps": k}
+            gather = {cfg["unit"].replace("/s", "_per_s_with_allgather"): round(world * B * k / el, 1),
+                      "ms_per_step_with_allgather": round(1e3 * el / k, 3), "allgather_ms": round(1e3 * el_g / k, 3),
+                      "received_bytes_per_rank": recv, "gathered_GB_per_s_per_rank": round(recv * k / el_g / 1e9, 1),
+                      "frac_of_xgmi_7x153GBs": round(recv * k / el_g / 1e9 / XGMI_PEAK_GBS, 4), "steps": k}
+            gather["clips_per_s_with_allgather"] = gather[cfg["unit"].replace("/s", "_per_s_with_allgather")]
             del full
         except Exception as exc:      # the headline measurement above is complete: report it whatever happens here
             gather = {"error": repr(exc)}
 
     if rank == 0:
-        achieved = BYTES_PER_CLIP * B / (kernel_avg_ms * 1e-3) / 1e9
-        traffic = load_traffic() if B == 4096 else None
+        achieved = cfg["bytes_per_unit"] * B / (kernel_avg_ms * 1e-3) / 1e9
+        traffic, traffic_note = (None, "no PMC profile for this configuration")
+        if args.config == "vgg4096" and B == 4096:
+            traffic, traffic_note = load_traffic(kernel_avg_ms)
         res = {
-            "metric": "clips/sec (10 s 16 kHz -> log-mel) per node",
+            "metric": cfg["metric"],
             "value": round(world * B * args.steps / elapsed, 1),
-            "unit": "clips/s",
+            "unit": cfg["unit"],
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -171,19 +281,19 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "VGGSound 10 s 16 kHz mono clips -> kaldi 128-bin log-mel, cut to 384 frames, "
-                                   "normalised (BASELINE configs[1])",
-                       "batch_per_gpu": B, "clip_samples": CLIP_SAMPLES, "n_fft": 512, "win": 400, "hop": 400,
-                       "n_mel": N_MEL, "out": [OUT_FRAMES, N_MEL], "parallelism": f"batch-sharded x{world}, no collective"},
+            "config": {"workload": cfg["workload"], "name": args.config, "batch_per_gpu": B, "samples_per_unit": n,
+                       "out": list(cfg["out"]), "parallelism": f"batch-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "fbank512_kernel", "kernel_avg_ms": round(kernel_avg_ms, 4),
+                         "kernel": cfg["kernel"], "kernel_avg_ms": round(kernel_avg_ms, 4),
                          "kernel_min_ms": round(kernel_ms[0], 4), "kernel_median_ms": round(kernel_ms[len(kernel_ms) // 2], 4),
-                         "algorithmic_bytes_per_clip": BYTES_PER_CLIP, "clips_per_launch": B},
+                         "algorithmic_bytes_per_unit": cfg["bytes_per_unit"], "units_per_launch": B},
         }
+        if traffic_note:
+            res["roofline"]["traffic_note"] = traffic_note
         if gather is not None:
             res["allgather"] = gather
-        if world == 1 and not args.no_secondary:
+        if world == 1 and not args.no_secondary and args.config == "vgg4096":
             # the other benchmark configurations that fit one GPU, a few launches each (not part of `value`)
             del x, out
             torch.cuda.empty_cache()

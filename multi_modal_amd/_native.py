@@ -75,48 +75,51 @@ def library_path() -> str:
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 
 
+def bind_library(path: str):
+    """Load one build of libmmfe.so from `path` and declare the prototypes (no caching)."""
+    if not os.path.exists(path):
+        raise MmfeError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C multi_modal_amd/csrc`. There is no CPU fallback.")
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:  # missing ROCm runtime etc.
+        raise MmfeError(f"cannot load {path}: {e}") from e
+    c_i64, c_f_p = ctypes.c_int64, ctypes.c_void_p
+    lib.mmfe_abi_version.restype = ctypes.c_int
+    lib.mmfe_abi_version.argtypes = []
+    lib.mmfe_last_error.restype = ctypes.c_char_p
+    lib.mmfe_last_error.argtypes = []
+    lib.mmfe_device_count.restype = ctypes.c_int
+    lib.mmfe_device_count.argtypes = []
+    lib.mmfe_spec_out_shape.restype = ctypes.c_int
+    lib.mmfe_spec_out_shape.argtypes = [ctypes.POINTER(MmfeSpec), c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]
+    lib.mmfe_plan_create.restype = ctypes.c_int
+    lib.mmfe_plan_create.argtypes = [ctypes.POINTER(MmfeSpec), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    lib.mmfe_plan_destroy.restype = ctypes.c_int
+    lib.mmfe_plan_destroy.argtypes = [ctypes.c_void_p]
+    lib.mmfe_run.restype = ctypes.c_int
+    lib.mmfe_run.argtypes = [ctypes.c_void_p, c_f_p, c_i64, c_i64, c_i64, c_f_p, ctypes.c_void_p]
+    lib.mmfe_run_slices.restype = ctypes.c_int
+    lib.mmfe_run_slices.argtypes = [ctypes.c_void_p, c_f_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                    c_i64, c_i64, c_f_p, ctypes.c_void_p]
+    lib.mmfe_feature_sums.restype = ctypes.c_int
+    lib.mmfe_feature_sums.argtypes = [c_f_p, c_i64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.mmfe_plan_kernel.restype = ctypes.c_char_p
+    lib.mmfe_plan_kernel.argtypes = [ctypes.c_void_p]
+    if lib.mmfe_abi_version() != ABI_VERSION:
+        raise MmfeError(f"{path} has ABI version {lib.mmfe_abi_version()}, the Python side expects {ABI_VERSION}")
+    return lib
+
+
 def load_library():
     """Load libmmfe.so once and declare the prototypes.  Raises MmfeError when it is missing."""
     global _lib
     with _lib_lock:
-        if _lib is not None:
-            return _lib
-        path = library_path()
-        if not os.path.exists(path):
-            raise MmfeError(
-                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                f"or `make -C multi_modal_amd/csrc`. There is no CPU fallback.")
-        try:
-            lib = ctypes.CDLL(path)
-        except OSError as e:  # missing ROCm runtime etc.
-            raise MmfeError(f"cannot load {path}: {e}") from e
-        c_i64, c_i32, c_f_p = ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p
-        lib.mmfe_abi_version.restype = ctypes.c_int
-        lib.mmfe_abi_version.argtypes = []
-        lib.mmfe_last_error.restype = ctypes.c_char_p
-        lib.mmfe_last_error.argtypes = []
-        lib.mmfe_device_count.restype = ctypes.c_int
-        lib.mmfe_device_count.argtypes = []
-        lib.mmfe_spec_out_shape.restype = ctypes.c_int
-        lib.mmfe_spec_out_shape.argtypes = [ctypes.POINTER(MmfeSpec), c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]
-        lib.mmfe_plan_create.restype = ctypes.c_int
-        lib.mmfe_plan_create.argtypes = [ctypes.POINTER(MmfeSpec), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                         ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
-        lib.mmfe_plan_destroy.restype = ctypes.c_int
-        lib.mmfe_plan_destroy.argtypes = [ctypes.c_void_p]
-        lib.mmfe_run.restype = ctypes.c_int
-        lib.mmfe_run.argtypes = [ctypes.c_void_p, c_f_p, c_i64, c_i64, c_i64, c_f_p, ctypes.c_void_p]
-        lib.mmfe_run_slices.restype = ctypes.c_int
-        lib.mmfe_run_slices.argtypes = [ctypes.c_void_p, c_f_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                        c_i64, c_i64, c_f_p, ctypes.c_void_p]
-        lib.mmfe_feature_sums.restype = ctypes.c_int
-        lib.mmfe_feature_sums.argtypes = [c_f_p, c_i64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
-        lib.mmfe_plan_kernel.restype = ctypes.c_char_p
-        lib.mmfe_plan_kernel.argtypes = [ctypes.c_void_p]
-        if lib.mmfe_abi_version() != ABI_VERSION:
-            raise MmfeError(f"{path} has ABI version {lib.mmfe_abi_version()}, the Python side expects {ABI_VERSION}")
-        _lib = lib
-        return lib
+        if _lib is None:
+            _lib = bind_library(library_path())
+        return _lib
 
 
 def last_error() -> str:

@@ -43,7 +43,7 @@ constexpr int kPGuard = 8;                   // floats in front of the power spe
 #define MMFE_FBANK_WAVES 4
 #endif
 #ifndef MMFE_FBANK_MIN_WAVES_PER_SIMD
-#define MMFE_FBANK_MIN_WAVES_PER_SIMD 3
+#define MMFE_FBANK_MIN_WAVES_PER_SIMD 4      // 4 blocks of 4 waves per CU: 128 VGPRs per lane, 4 x 40064 B of LDS
 #endif
 // output stores: the feature tensor is far larger than the caches, so it can bypass them (1) or not (0)
 #ifndef MMFE_FBANK_NTLOAD
@@ -62,8 +62,9 @@ typedef float mmfe_f32x4 __attribute__((ext_vector_type(4)));
 #endif
 
 #ifndef MMFE_TWIDDLE_REGS
-#define MMFE_TWIDDLE_REGS 1   // 1: first-half twiddles live in 30 VGPRs instead of LDS
-#endif
+#define MMFE_TWIDDLE_REGS 2   // where the first-half twiddles W256^(b*c) live.  2: a [c][b] table in LDS (the 16 lanes of a frame read 128
+#endif                        // contiguous bytes, conflict-free), which frees 30 VGPRs and lets a fourth wave per SIMD in: 2.7 % faster than
+                              // 1: 30 VGPRs per lane (3 waves per SIMD);  0: the W256 table in LDS indexed b*c (bank conflicts, slowest)
 #ifndef MMFE_MEL_ACC_A
 #define MMFE_MEL_ACC_A 1
 #endif
@@ -208,7 +209,11 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
     float* s_mel_w = reinterpret_cast<float*>(s_mel_start + (kMfmaMel ? 0 : kMaxPass * 16));   // VALU mel only
     char* s_work = reinterpret_cast<char*>(s_mel_w + (kMfmaMel ? 0 : p.mel_rows * 16));
 
+#if MMFE_TWIDDLE_REGS == 2
+    for (int i = threadIdx.x; i < 240; i += blockDim.x) s_tw_stage[i] = p.tw_stage[(i & 15) * ((i >> 4) + 1)];      // [c - 1][b] = W256^(b*c)
+#else
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_tw_stage[i] = p.tw_stage[i];
+#endif
     for (int i = threadIdx.x; i < kTwPostEntries; i += blockDim.x) s_tw_post[i] = p.tw_post[i];
     for (int i = threadIdx.x; i < 512; i += blockDim.x) s_win[i] = p.window[i];
     if (!kMfmaMel) {
@@ -255,7 +260,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
     };
 
     const Elem* safe = row_ptr_as<Elem>(p.src, 0);      // first samples of row 0: always readable
-#if MMFE_TWIDDLE_REGS
+#if MMFE_TWIDDLE_REGS == 1
     float2 twr[15];                             // W256^(b*c), c = 1..15: resident for the life of the kernel
 #pragma unroll
     for (int c = 1; c < 16; ++c) twr[c - 1] = p.tw_stage[b * c];
@@ -320,8 +325,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             float2 val = y[fft16_pos(c)];
-#if MMFE_TWIDDLE_REGS
+#if MMFE_TWIDDLE_REGS == 1
             if (c > 0) val = cmul(val, twr[c - 1]);
+#elif MMFE_TWIDDLE_REGS == 2
+            if (c > 0) val = cmul(val, s_tw_stage[(c - 1) * 16 + b]);
 #else
             if (c > 0) val = cmul(val, s_tw_stage[b * c]);
 #endif
@@ -480,12 +487,14 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
 #endif
 }
 
+// `want` blocks cover the batch once; the grid is persistent, at most `per_cu` blocks on each CU of the current device.
 template <bool PCM, int NA, bool VEC2, bool EXACT, int NGA, int NGB>
-int launch_variant(const FbankArgs& args, int grid, size_t lds, hipStream_t stream) {
-    int resident = 0, cus = 0;      // raises the variant's dynamic-LDS limit on this device (once); the grid is sized by the caller
+int launch_variant(const FbankArgs& args, int64_t want, int per_cu, size_t lds, hipStream_t stream) {
+    int resident = 0, cus = 0;      // raises the variant's dynamic-LDS limit on this device (once) and returns the cached CU count
     const int prc = kernel_prepare(reinterpret_cast<const void*>(&fbank512_kernel<PCM, NA, VEC2, EXACT, NGA, NGB>), 64 * kWavesPerBlock, lds,
                                    &resident, &cus);
     if (prc) return prc;
+    const int grid = (int)std::min<int64_t>(want, (int64_t)cus * per_cu);
 #ifdef MMFE_STAMPS
     FbankArgs targs = args;
     const size_t n_st = (size_t)grid * kWavesPerBlock * 8;
@@ -658,6 +667,8 @@ int fbank512_prepare(Plan& plan) {
     // matrix-pipe mel form when the bank fits an instantiated shape (MMFE_MEL_FORM=valu forces the VALU form,
     // MMFE_MEL_ALIGN=1 starts every bin run at blk (mod 8), which makes the LDS operand reads bank-conflict-free
     // at the price of longer runs; measured slower than the shorter unaligned runs, so it is off by default)
+    // tuning knobs are read here, once per plan, never on the launch path
+    if (const char* e = std::getenv("MMFE_FBANK_BLOCKS_PER_CU")) plan.tune_blocks_per_cu = std::atoi(e);     // fewer resident blocks per CU
     const char* form = std::getenv("MMFE_MEL_FORM");
     const char* al = std::getenv("MMFE_MEL_ALIGN");
     const bool want_mfma = !(form != nullptr && std::string(form) == "valu");
@@ -751,18 +762,11 @@ int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
         set_error("fbank512: mel tap table does not fit in LDS (%zu bytes)", lds);
         return MMFE_EINVAL;
     }
-    int dev = 0, cus = 256;
-    MMFE_HIP_CHECK(hipGetDevice(&dev));
-    MMFE_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int blocks_per_cu = std::max<int>(1, (int)((160 * 1024) / lds));
     const int64_t want = (quads + kWavesPerBlock - 1) / kWavesPerBlock;
     const int by_waves = std::max(1, (4 * MMFE_FBANK_MIN_WAVES_PER_SIMD) / kWavesPerBlock);
     int per_cu = std::min(blocks_per_cu, by_waves);
-    if (const char* e = std::getenv("MMFE_FBANK_BLOCKS_PER_CU")) {     // tuning: fewer resident blocks (the grid is persistent)
-        const int v = std::atoi(e);
-        if (v >= 1 && v < per_cu) per_cu = v;
-    }
-    const int grid = (int)std::min<int64_t>(want, (int64_t)cus * per_cu);
+    if (plan.tune_blocks_per_cu >= 1 && plan.tune_blocks_per_cu < per_cu) per_cu = plan.tune_blocks_per_cu;
 
     // one load per 2-sample slice needs every frame start aligned to the slice (8 bytes of floats, 4 of PCM)
     const bool pcm = s.in_dtype == MMFE_IN_S16;
@@ -774,13 +778,13 @@ int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
 #define MMFE_FBANK_DISPATCH(NGA_, NGB_)                                                                         \
     if (nga == NGA_ && ngb == NGB_) {                                                                           \
         if (pcm) {                                                                                              \
-            if (na == 13 && vec2) return launch_variant<true, 13, true, true, NGA_, NGB_>(a, grid, lds, stream); \
-            return vec2 ? launch_variant<true, 16, true, false, NGA_, NGB_>(a, grid, lds, stream)               \
-                        : launch_variant<true, 16, false, false, NGA_, NGB_>(a, grid, lds, stream);             \
+            if (na == 13 && vec2) return launch_variant<true, 13, true, true, NGA_, NGB_>(a, want, per_cu, lds, stream); \
+            return vec2 ? launch_variant<true, 16, true, false, NGA_, NGB_>(a, want, per_cu, lds, stream)               \
+                        : launch_variant<true, 16, false, false, NGA_, NGB_>(a, want, per_cu, lds, stream);             \
         }                                                                                                       \
-        if (na == 13 && vec2) return launch_variant<false, 13, true, true, NGA_, NGB_>(a, grid, lds, stream);   \
-        return vec2 ? launch_variant<false, 16, true, false, NGA_, NGB_>(a, grid, lds, stream)                  \
-                    : launch_variant<false, 16, false, false, NGA_, NGB_>(a, grid, lds, stream);                \
+        if (na == 13 && vec2) return launch_variant<false, 13, true, true, NGA_, NGB_>(a, want, per_cu, lds, stream);   \
+        return vec2 ? launch_variant<false, 16, true, false, NGA_, NGB_>(a, want, per_cu, lds, stream)                  \
+                    : launch_variant<false, 16, false, false, NGA_, NGB_>(a, want, per_cu, lds, stream);                \
     }
     MMFE_FBANK_DISPATCH(2, 7)
     MMFE_FBANK_DISPATCH(3, 8)

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""A/B timing of several builds of libmmfe.so on the VGGSound log-mel configuration, in ONE process with
+interleaved rounds (separate processes add variance that looks like a kernel property).
+
+    python scripts/ab_fbank.py [--batch 4096] [--rounds 6] [--launches 20] name=path.so [name=path.so ...]
+
+Every build gets its own plan; round r times `launches` launches of every build in turn with HIP events.
+Prints per build: median / min of the per-launch times, the median of the per-round medians, and the maximum
+difference of its output from the first build's (a variant that changes the arithmetic shows up here).
+"""
+import argparse
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from multi_modal_amd import _native as N          # noqa: E402
+from multi_modal_amd import kaldi, plans, vggsound  # noqa: E402
+
+
+def build_plan(path, device, in_dtype=N.IN_F32):
+    """The VGGSound plan of kaldi._fbank_plan, created through the library at `path`."""
+    N._lib = N.bind_library(path)
+    plans._plans.clear()            # plans of the previous library stay alive in the caller's list
+    kw = dict(vggsound._KW)
+    plan = kaldi._fbank_plan(device, sample_frequency=kw["sample_frequency"], frame_length=25.0, frame_shift=kw["frame_shift"],
+                             num_mel_bins=kw["num_mel_bins"], window_type=kw["window_type"], blackman_coeff=0.42,
+                             preemphasis_coefficient=0.97, remove_dc_offset=True, round_to_power_of_two=True, low_freq=20.0,
+                             high_freq=0.0, use_log_fbank=True, out_frames=kw["out_frames"], pad_value=kw["pad_value"],
+                             out_shift=kw["out_shift"], out_scale=kw["out_scale"], in_dtype=in_dtype)
+    return plan
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--rounds", type=int, default=6)
+    ap.add_argument("--launches", type=int, default=20)
+    ap.add_argument("--samples", type=int, default=160000)
+    ap.add_argument("builds", nargs="+", help="name=path pairs")
+    args = ap.parse_args()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    x = (0.1 * torch.randn(args.batch, args.samples, device=dev, generator=g)).clamp_(-1, 1)
+    names, plist, outs = [], [], []
+    for b in args.builds:
+        name, path = b.split("=", 1)
+        names.append(name)
+        plist.append(build_plan(os.path.abspath(path), 0))
+        outs.append(torch.empty(args.batch, 384, 128, device=dev))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def launch(i):
+        plist[i].run_ptr(x.data_ptr(), x.stride(0), args.batch, args.samples, outs[i].data_ptr(), stream)
+
+    for i in range(len(plist)):
+        launch(i)
+    torch.cuda.synchronize()
+    diffs = [float((outs[i] - outs[0]).abs().max()) for i in range(len(plist))]
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.5:       # leave the idle clock state
+        for i in range(len(plist)):
+            for _ in range(10):
+                launch(i)
+        torch.cuda.synchronize()
+    per = [[] for _ in plist]
+    round_med = [[] for _ in plist]
+    for r in range(args.rounds):
+        order = list(range(len(plist)))
+        if r % 2:
+            order.reverse()
+        for i in order:
+            for _ in range(3):
+                launch(i)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.launches)]
+            for s, e in evs:
+                s.record()
+                launch(i)
+                e.record()
+            torch.cuda.synchronize()
+            ts = [s.elapsed_time(e) for s, e in evs]
+            per[i] += ts
+            round_med[i].append(statistics.median(ts))
+    base = statistics.median(round_med[0])
+    print(f"{'build':<24} {'median ms':>10} {'min ms':>9} {'med of round medians':>21} {'vs first':>9} {'max|d| vs first':>16}")
+    for i, name in enumerate(names):
+        m = statistics.median(round_med[i])
+        print(f"{name:<24} {statistics.median(per[i]):>10.4f} {min(per[i]):>9.4f} {m:>21.4f} {m / base:>9.3f} {diffs[i]:>16.3e}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -255,7 +255,11 @@ def test_bench_cpu_baseline_fields():
     spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    assert bench.BYTES_PER_CLIP == 811008
-    r = bench.cpu_baseline(budget_s=0.2, max_clips=3)
-    assert r["unit"] == "clips/s" and r["cores"] == 1 and r["kind"] == "port" and r["value"] > 0 and "clips" in r["sample"]
-
+    assert bench.BYTES_PER_CLIP == 811008 and bench.BYTES_PER_UTT == 2880000
+    r = bench.cpu_baseline(budget_s=0.4, max_clips=3, legs=("1_thread", "4_workers"))
+    assert r["unit"] == "clips/s" and r["kind"] == "port" and "clips" in r["sample"]
+    assert r["legs"]["1_thread"]["cores"] == 1 and r["legs"]["1_thread"]["value"] > 0
+    assert r["legs"]["4_workers"]["cores"] == 4 and r["legs"]["4_workers"]["value"] > 0
+    assert r["cores"] == 4 and r["value"] == r["legs"]["4_workers"]["value"]       # the leg the reference's DataLoader corresponds to
+    assert 1 <= bench.host_core_share() <= 16
+    assert set(bench.CONFIGS) == {"vgg4096", "vgg200k", "logmel"}
