@@ -170,6 +170,18 @@ int mmfe_plan_destroy(mmfe_plan* plan);
 int mmfe_run(const mmfe_plan* plan, const void* in, int64_t in_stride, int64_t n_rows, int64_t n_samples,
              void* out, void* hip_stream);
 
+/* mmfe_run for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc): same arguments, same results.  No counterpart in the reference.  The one scratch buffer the
+ * kernels need, the per-row maxima and minima of clamp_below_max plans, is a static device array inside the library
+ * (2 x MMFE_NOALLOC_MAX_ROWS floats = 512 KiB per GPU, held until the process ends) instead of the plan's own buffer;
+ * the call allocates and frees nothing.  Limits: a clamp_below_max plan takes at most MMFE_NOALLOC_MAX_ROWS rows per
+ * call (more: MMFE_EINVAL, nothing is launched); every call on a GPU uses that GPU's one array, so two calls with
+ * clamp_below_max plans that overlap on one GPU race (issue them on one stream).  Plans without clamp_below_max use no
+ * scratch and run exactly as under mmfe_run. */
+#define MMFE_NOALLOC_MAX_ROWS 65536
+int mmfe_run_noalloc(const mmfe_plan* plan, const void* in, int64_t in_stride, int64_t n_rows, int64_t n_samples,
+                     void* out, void* hip_stream);
+
 /* Same transform, but row r is the slice [offsets[r], offsets[r] + n_samples) of recording
  * rec_index[r] in a packed device buffer (recording i starts rec_start[i] elements into recs).  Stands for
  * the slicing in EPICKitchen._extract_sound_feature (epic_kitchen.py:128-154) feeding _log_specgram. */

@@ -25,10 +25,11 @@ LOG_NONE, LOG_LN_MAX, LOG_LN_ADD, LOG_LOG10_MAX = 0, 1, 2, 3
 LAYOUT_TIME_MAJOR, LAYOUT_FEAT_MAJOR = 0, 1
 OUT_F32, OUT_F16, OUT_BF16 = 0, 1, 2
 IN_F32, IN_S16 = 0, 1
+NOALLOC_MAX_ROWS = 65536
 
 EXPORTED_SYMBOLS = (
     "mmfe_abi_version", "mmfe_last_error", "mmfe_device_count", "mmfe_spec_out_shape",
-    "mmfe_plan_create", "mmfe_plan_destroy", "mmfe_run", "mmfe_run_slices", "mmfe_feature_sums",
+    "mmfe_plan_create", "mmfe_plan_destroy", "mmfe_run", "mmfe_run_noalloc", "mmfe_run_slices", "mmfe_feature_sums",
     "mmfe_plan_kernel",
 )
 
@@ -101,6 +102,8 @@ def bind_library(path: str):
     lib.mmfe_plan_destroy.argtypes = [ctypes.c_void_p]
     lib.mmfe_run.restype = ctypes.c_int
     lib.mmfe_run.argtypes = [ctypes.c_void_p, c_f_p, c_i64, c_i64, c_i64, c_f_p, ctypes.c_void_p]
+    lib.mmfe_run_noalloc.restype = ctypes.c_int
+    lib.mmfe_run_noalloc.argtypes = [ctypes.c_void_p, c_f_p, c_i64, c_i64, c_i64, c_f_p, ctypes.c_void_p]
     lib.mmfe_run_slices.restype = ctypes.c_int
     lib.mmfe_run_slices.argtypes = [ctypes.c_void_p, c_f_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                     c_i64, c_i64, c_f_p, ctypes.c_void_p]
@@ -186,6 +189,11 @@ class Plan:
     def run_ptr(self, in_ptr: int, in_stride: int, n_rows: int, n_samples: int, out_ptr: int, stream: int = 0) -> None:
         check(self._lib.mmfe_run(self._handle, in_ptr, int(in_stride), int(n_rows), int(n_samples), out_ptr,
                                  ctypes.c_void_p(stream) if stream else None), "mmfe_run")
+
+    def run_noalloc_ptr(self, in_ptr: int, in_stride: int, n_rows: int, n_samples: int, out_ptr: int, stream: int = 0) -> None:
+        """mmfe_run_noalloc: as run_ptr, with the clamp scratch in the library's static device array (no allocation)."""
+        check(self._lib.mmfe_run_noalloc(self._handle, in_ptr, int(in_stride), int(n_rows), int(n_samples), out_ptr,
+                                         ctypes.c_void_p(stream) if stream else None), "mmfe_run_noalloc")
 
     def run_slices_ptr(self, recs_ptr: int, rec_start_ptr: int, rec_index_ptr: int, offsets_ptr: int, n_rows: int,
                        n_samples: int, out_ptr: int, stream: int = 0) -> None:

@@ -466,25 +466,25 @@ __global__ void clamp_affine_kernel(float* out, const int* rowmax, int64_t per_r
 
 }  // namespace
 
-int rowmax_init_launch(const Plan& plan, int64_t n_rows, hipStream_t stream) {
-    if (plan.d_rowmax == nullptr || n_rows > plan.rowmax_capacity) {
-        set_error("clamp_below_max supports at most %lld rows per call", (long long)plan.rowmax_capacity);
+int rowmax_init_launch(const ClampScratch& cs, int64_t n_rows, hipStream_t stream) {
+    if (cs.base == nullptr || n_rows > cs.capacity) {
+        set_error("clamp_below_max: %lld rows in one call, this entry point handles at most %lld", (long long)n_rows, (long long)cs.capacity);
         return MMFE_EINVAL;
     }
     hipLaunchKernelGGL(rowmax_init_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream,
-                       reinterpret_cast<int*>(plan.d_rowmax), (int)n_rows, (int)plan.rowmax_capacity);
+                       reinterpret_cast<int*>(cs.base), (int)n_rows, (int)cs.capacity);
     MMFE_HIP_CHECK(hipGetLastError());
     return MMFE_OK;
 }
 
-int clamp_affine_launch(const Plan& plan, float* out, int64_t n_rows, int64_t per_row, hipStream_t stream) {
+int clamp_affine_launch(const Plan& plan, const ClampScratch& cs, float* out, int64_t n_rows, int64_t per_row, hipStream_t stream) {
     const mmfe_spec& s = plan.spec;
     int dev = 0, cus = 256;
     MMFE_HIP_CHECK(hipGetDevice(&dev));
     MMFE_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int64_t total = per_row * n_rows;
     const int grid = (int)std::min<int64_t>((total + 255) / 256, (int64_t)cus * 16);
-    hipLaunchKernelGGL(clamp_affine_kernel, dim3(grid), dim3(256), 0, stream, out, reinterpret_cast<const int*>(plan.d_rowmax),
+    hipLaunchKernelGGL(clamp_affine_kernel, dim3(grid), dim3(256), 0, stream, out, reinterpret_cast<const int*>(cs.base),
                        per_row, total, s.clamp_below_max, s.out_shift, s.out_scale);
     MMFE_HIP_CHECK(hipGetLastError());
     return MMFE_OK;
@@ -530,7 +530,7 @@ int dftgen_prepare(Plan& plan) {
 }
 
 int dftgen_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames_natural,
-                  int64_t out_frames, float* out, hipStream_t stream) {
+                  int64_t out_frames, float* out, const ClampScratch& cs, hipStream_t stream) {
     const mmfe_spec& s = plan.spec;
     const int64_t frames_valid = std::min(n_frames_natural, out_frames);
     if (n_rows <= 0 || frames_valid <= 0) return MMFE_OK;
@@ -561,9 +561,9 @@ int dftgen_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
 
     const bool clamp = s.clamp_below_max > 0.f;
     if (clamp) {
-        int rc = rowmax_init_launch(plan, n_rows, stream);
+        int rc = rowmax_init_launch(cs, n_rows, stream);
         if (rc) return rc;
-        a.rowmax = plan.d_rowmax;
+        a.rowmax = cs.base;
     }
     if (dftmm_supports(s)) {
         const size_t mm_lds = (size_t)s.n_fft * 32 + (size_t)s.win_len * 8;
@@ -595,7 +595,7 @@ int dftgen_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
     if (pcm) hipLaunchKernelGGL(dftgen_kernel<int16_t>, dim3(grid), dim3(kThreads), lds, stream, a);
     else hipLaunchKernelGGL(dftgen_kernel<float>, dim3(grid), dim3(kThreads), lds, stream, a);
     MMFE_HIP_CHECK(hipGetLastError());
-    if (clamp) return clamp_affine_launch(plan, out, n_rows, out_frames * a.n_feat, stream);
+    if (clamp) return clamp_affine_launch(plan, cs, out, n_rows, out_frames * a.n_feat, stream);
     return MMFE_OK;
 }
 

@@ -150,7 +150,33 @@ void free_plan(Plan* p) {
     delete p;
 }
 
-int run_common(const Plan* plan, const RowSource& src, int64_t n_rows, int64_t n_samples, void* out_any, void* hip_stream) {
+// ---- mmfe_run_noalloc: the per-row extremes of clamp_below_max live in a static device array -------------------
+constexpr int64_t kNoAllocMaxRows = MMFE_NOALLOC_MAX_ROWS;
+constexpr int kNoAllocMaxDevices = 64;
+// Ordered-int maxima [0, kNoAllocMaxRows), minima [kNoAllocMaxRows, 2 * kNoAllocMaxRows): 512 KiB, resident on every GPU
+// the library runs on until the process ends.  In host code this name is only a handle for hipGetSymbolAddress; the
+// address kernels and memsets use is the per-device pointer obtained below.
+static __device__ __align__(256) float g_noalloc_scratch[2 * kNoAllocMaxRows];
+
+// Device address of g_noalloc_scratch on the CURRENT device (each GPU holds its own copy at its own address);
+// looked up once per device.
+int noalloc_scratch_ptr(int device, float** out) {
+    static std::mutex mu;
+    static float* ptrs[kNoAllocMaxDevices] = {nullptr};
+    if (device < 0 || device >= kNoAllocMaxDevices) { set_error("device %d beyond the %d this entry point serves", device, kNoAllocMaxDevices); return MMFE_EINVAL; }
+    std::lock_guard<std::mutex> lock(mu);
+    if (ptrs[device] == nullptr) {
+        void* p = nullptr;
+        MMFE_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(g_noalloc_scratch)));
+        if (p == nullptr) { set_error("hipGetSymbolAddress returned NULL for the static scratch"); return MMFE_EHIP; }
+        ptrs[device] = static_cast<float*>(p);
+    }
+    *out = ptrs[device];
+    return MMFE_OK;
+}
+
+int run_common(const Plan* plan, const RowSource& src, int64_t n_rows, int64_t n_samples, void* out_any, void* hip_stream,
+               bool static_scratch = false) {
     float* out = static_cast<float*>(out_any);      // every kernel family but the n_fft 512 one stores floats (checked at plan creation)
     if (plan == nullptr) { set_error("plan is NULL"); return MMFE_EINVAL; }
     if (n_rows < 0 || n_samples < 0) { set_error("negative size"); return MMFE_EINVAL; }
@@ -164,10 +190,20 @@ int run_common(const Plan* plan, const RowSource& src, int64_t n_rows, int64_t n
     DeviceGuard guard(plan->device);
     if (!guard.ok) { set_error("cannot make device %d current", plan->device); return MMFE_EHIP; }
     hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+    ClampScratch cs{plan->d_rowmax, plan->rowmax_capacity};
+    if (static_scratch) {
+        cs.capacity = kNoAllocMaxRows;
+        if ((rc = noalloc_scratch_ptr(plan->device, &cs.base))) return rc;
+        if (s.clamp_below_max > 0.f && n_rows > kNoAllocMaxRows) {
+            set_error("mmfe_run_noalloc: %lld rows with clamp_below_max, the static scratch holds %lld (use mmfe_run, or split the batch)",
+                      (long long)n_rows, (long long)kNoAllocMaxRows);
+            return MMFE_EINVAL;
+        }
+    }
     switch (plan->impl) {
         case IMPL_FBANK512: rc = fbank512_launch(*plan, src, n_rows, n_samples, natural, frames, out_any, stream); break;
-        case IMPL_DFT_GENERIC: rc = dftgen_launch(*plan, src, n_rows, n_samples, natural, frames, out, stream); break;
-        case IMPL_RFFT400: rc = rfft400_launch(*plan, src, n_rows, n_samples, natural, frames, out, stream); break;
+        case IMPL_DFT_GENERIC: rc = dftgen_launch(*plan, src, n_rows, n_samples, natural, frames, out, cs, stream); break;
+        case IMPL_RFFT400: rc = rfft400_launch(*plan, src, n_rows, n_samples, natural, frames, out, cs, stream); break;
         case IMPL_STFT32: rc = stft32_launch(*plan, src, n_rows, n_samples, frames, out, stream); break;
         case IMPL_FRAME: rc = frame_launch(*plan, src, n_rows, n_samples, frames, out, stream); break;
         default: set_error("plan has no implementation"); rc = MMFE_EINVAL;
@@ -328,6 +364,13 @@ int mmfe_run(const mmfe_plan* plan, const void* in, int64_t in_stride, int64_t n
     if (in_stride < n_samples && n_rows > 1) { set_error("in_stride (%lld) smaller than n_samples (%lld)", (long long)in_stride, (long long)n_samples); return MMFE_EINVAL; }
     RowSource src{in, in_stride, nullptr, nullptr, nullptr};
     return run_common(reinterpret_cast<const Plan*>(plan), src, n_rows, n_samples, out, hip_stream);
+}
+
+int mmfe_run_noalloc(const mmfe_plan* plan, const void* in, int64_t in_stride, int64_t n_rows, int64_t n_samples, void* out,
+                     void* hip_stream) {
+    if (in_stride < n_samples && n_rows > 1) { set_error("in_stride (%lld) smaller than n_samples (%lld)", (long long)in_stride, (long long)n_samples); return MMFE_EINVAL; }
+    RowSource src{in, in_stride, nullptr, nullptr, nullptr};
+    return run_common(reinterpret_cast<const Plan*>(plan), src, n_rows, n_samples, out, hip_stream, true);
 }
 
 int mmfe_run_slices(const mmfe_plan* plan, const void* recs, const int64_t* rec_start, const int32_t* rec_index,

@@ -115,6 +115,13 @@ struct Plan {
 
 enum Impl { IMPL_FBANK512 = 1, IMPL_STFT32 = 2, IMPL_DFT_GENERIC = 3, IMPL_FRAME = 4, IMPL_RFFT400 = 5 };
 
+// Where a clamp_below_max call keeps its per-row extremes (ordered-int maxima at [0, capacity), minima at
+// [capacity, 2*capacity)): the plan's own buffer, or the library's static device array (mmfe_run_noalloc).
+struct ClampScratch {
+    float* base;
+    int64_t capacity;
+};
+
 // launchers (one per translation unit)
 int fbank512_prepare(Plan& plan);
 int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames_natural,
@@ -126,16 +133,16 @@ int stft32_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
 
 int dftgen_prepare(Plan& plan);
 int dftgen_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames_natural,
-                  int64_t out_frames, float* out, hipStream_t stream);
+                  int64_t out_frames, float* out, const ClampScratch& cs, hipStream_t stream);
 
 // per-row extremes + clamp pass of clamp_below_max: out = (max(out, rowmax - c) + out_shift) * out_scale
-int rowmax_init_launch(const Plan& plan, int64_t n_rows, hipStream_t stream);
-int clamp_affine_launch(const Plan& plan, float* out, int64_t n_rows, int64_t per_row, hipStream_t stream);
+int rowmax_init_launch(const ClampScratch& cs, int64_t n_rows, hipStream_t stream);
+int clamp_affine_launch(const Plan& plan, const ClampScratch& cs, float* out, int64_t n_rows, int64_t per_row, hipStream_t stream);
 
 bool rfft400_supports(const mmfe_spec& spec);
 int rfft400_prepare(Plan& plan);
 int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames_natural,
-                   int64_t out_frames, float* out, hipStream_t stream);
+                   int64_t out_frames, float* out, const ClampScratch& cs, hipStream_t stream);
 
 int frame_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames,
                  float* out, hipStream_t stream);

@@ -607,7 +607,7 @@ int rfft400_prepare(Plan& plan) {
 }
 
 int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames_natural,
-                   int64_t out_frames, float* out, hipStream_t stream) {
+                   int64_t out_frames, float* out, const ClampScratch& cs, hipStream_t stream) {
     const mmfe_spec& s = plan.spec;
     const int64_t frames_valid = std::min(n_frames_natural, out_frames);
     if (n_rows <= 0 || frames_valid <= 0) return MMFE_OK;
@@ -638,10 +638,10 @@ int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64
     a.mel_dst = plan.d_r400_dst;
     a.mel_w = plan.d_mel4_w;
     if (clamp) {
-        int rc = rowmax_init_launch(plan, n_rows, stream);
+        int rc = rowmax_init_launch(cs, n_rows, stream);
         if (rc) return rc;
-        a.rowmax = reinterpret_cast<int*>(plan.d_rowmax);
-        a.rowmin = a.rowmax + plan.rowmax_capacity;
+        a.rowmax = reinterpret_cast<int*>(cs.base);
+        a.rowmin = a.rowmax + cs.capacity;
     }
     const bool pcm = s.in_dtype == MMFE_IN_S16;
     const bool vec = s.hop % 4 == 0 && a.shift % 4 == 0 && src.offsets == nullptr && src.stride % 4 == 0 &&
