@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define MMFE_ABI_VERSION 3
+#define MMFE_ABI_VERSION 4
 
 /* error codes */
 #define MMFE_OK            0
@@ -102,7 +102,9 @@ extern "C" {
 typedef struct mmfe_spec {
     int32_t struct_size;   /* = sizeof(mmfe_spec) */
     int32_t kind;          /* MMFE_KIND_* */
-    int32_t n_fft;         /* DFT length: any value in [2, 4096]; 512, 400 and (STFT_MAG) 32 have radix kernels */
+    int32_t n_fft;         /* DFT length in [2, 4096]; 512, 400 and (STFT_MAG) 32 have radix kernels.  Other lengths run on the
+                              any-length kernel, which needs 32*n_fft + 128*(win_len + 1) bytes of LDS (plus 64*(n_fft/2 + 2) when
+                              n_fft > 510): plans beyond the CU's 160 KiB (win_len near n_fft above about 850) are refused at creation */
     int32_t win_len;       /* number of window taps (<= n_fft); FRAME: frame_length */
     int32_t win_off;       /* position of tap 0 inside the n_fft-long DFT input (zeros elsewhere) */
     int32_t hop;
@@ -187,6 +189,21 @@ int mmfe_run_noalloc(const mmfe_plan* plan, const void* in, int64_t in_stride, i
  * the slicing in EPICKitchen._extract_sound_feature (epic_kitchen.py:128-154) feeding _log_specgram. */
 int mmfe_run_slices(const mmfe_plan* plan, const void* recs, const int64_t* rec_start, const int32_t* rec_index,
                     const int64_t* offsets, int64_t n_rows, int64_t n_samples, void* out, void* hip_stream);
+
+/* Ragged batches in ONE launch: row r holds row_len[r] samples (device array of n_rows ints, each clamped to
+ * [0, n_samples]); n_samples is the length of the longest row and fixes the output shape exactly as in mmfe_run.  Every
+ * row is transformed as if it were passed alone with its own length (its own padding at its own end, its own frame
+ * count); frames a shorter row does not have are filled like the frames beyond out_frames' natural count
+ * ((pad_value + out_shift) * out_scale).  Stands for a DataLoader batch that mixes lengths: the reference feeds
+ * interior (30 672-sample) and edge (30 696-sample) EPIC slices through the same _log_specgram
+ * (epic_kitchen.py:143-154, both give 256 frames) and pads VGGSound clips of any length to 384 frames
+ * (vggsound.py:48-56).  FBANK and LOGSPEC kinds without clamp_below_max.  The first win_len elements of `in` / `recs`
+ * must be readable (the kernels park masked lanes there). */
+int mmfe_run_ragged(const mmfe_plan* plan, const void* in, int64_t in_stride, const int32_t* row_len, int64_t n_rows,
+                    int64_t n_samples, void* out, void* hip_stream);
+int mmfe_run_slices_ragged(const mmfe_plan* plan, const void* recs, const int64_t* rec_start, const int32_t* rec_index,
+                           const int64_t* offsets, const int32_t* row_len, int64_t n_rows, int64_t n_samples, void* out,
+                           void* hip_stream);
 
 /* Sum and sum of squares (float64) of n device floats, accumulated into sums[0], sums[1] (device,
  * caller zeroes them).  Stands for the two DataLoader passes of cal_norm (vggsound.py:85-107). */

@@ -17,7 +17,7 @@ _lib = None
 _lib_lock = threading.Lock()
 
 # --- constants mirrored from include/mmfe.h -------------------------------------------------------
-ABI_VERSION = 3
+ABI_VERSION = 4
 KIND_FBANK, KIND_LOGSPEC, KIND_STFT_MAG, KIND_FRAME = 1, 2, 3, 4
 PAD_NONE, PAD_ZERO, PAD_REFLECT = 0, 1, 2
 FRAMES_SNIP, FRAMES_CENTER, FRAMES_SCIPY, FRAMES_CEIL = 0, 1, 2, 3
@@ -29,7 +29,7 @@ NOALLOC_MAX_ROWS = 65536
 
 EXPORTED_SYMBOLS = (
     "mmfe_abi_version", "mmfe_last_error", "mmfe_device_count", "mmfe_spec_out_shape",
-    "mmfe_plan_create", "mmfe_plan_destroy", "mmfe_run", "mmfe_run_noalloc", "mmfe_run_slices", "mmfe_feature_sums",
+    "mmfe_plan_create", "mmfe_plan_destroy", "mmfe_run", "mmfe_run_noalloc", "mmfe_run_slices", "mmfe_run_ragged", "mmfe_run_slices_ragged", "mmfe_feature_sums",
     "mmfe_plan_kernel",
 )
 
@@ -107,6 +107,11 @@ def bind_library(path: str):
     lib.mmfe_run_slices.restype = ctypes.c_int
     lib.mmfe_run_slices.argtypes = [ctypes.c_void_p, c_f_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                     c_i64, c_i64, c_f_p, ctypes.c_void_p]
+    lib.mmfe_run_ragged.restype = ctypes.c_int
+    lib.mmfe_run_ragged.argtypes = [ctypes.c_void_p, c_f_p, c_i64, ctypes.c_void_p, c_i64, c_i64, c_f_p, ctypes.c_void_p]
+    lib.mmfe_run_slices_ragged.restype = ctypes.c_int
+    lib.mmfe_run_slices_ragged.argtypes = [ctypes.c_void_p, c_f_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                           c_i64, c_i64, c_f_p, ctypes.c_void_p]
     lib.mmfe_feature_sums.restype = ctypes.c_int
     lib.mmfe_feature_sums.argtypes = [c_f_p, c_i64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     lib.mmfe_plan_kernel.restype = ctypes.c_char_p
@@ -200,6 +205,17 @@ class Plan:
         check(self._lib.mmfe_run_slices(self._handle, recs_ptr, rec_start_ptr, rec_index_ptr, offsets_ptr, int(n_rows),
                                         int(n_samples), out_ptr, ctypes.c_void_p(stream) if stream else None),
               "mmfe_run_slices")
+
+    def run_ragged_ptr(self, in_ptr: int, in_stride: int, row_len_ptr: int, n_rows: int, n_samples: int, out_ptr: int,
+                       stream: int = 0) -> None:
+        check(self._lib.mmfe_run_ragged(self._handle, in_ptr, int(in_stride), row_len_ptr, int(n_rows), int(n_samples), out_ptr,
+                                        ctypes.c_void_p(stream) if stream else None), "mmfe_run_ragged")
+
+    def run_slices_ragged_ptr(self, recs_ptr: int, rec_start_ptr: int, rec_index_ptr: int, offsets_ptr: int, row_len_ptr: int,
+                              n_rows: int, n_samples: int, out_ptr: int, stream: int = 0) -> None:
+        check(self._lib.mmfe_run_slices_ragged(self._handle, recs_ptr, rec_start_ptr, rec_index_ptr, offsets_ptr, row_len_ptr,
+                                               int(n_rows), int(n_samples), out_ptr, ctypes.c_void_p(stream) if stream else None),
+              "mmfe_run_slices_ragged")
 
     @property
     def kernel(self) -> str:

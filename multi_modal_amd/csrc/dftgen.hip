@@ -94,6 +94,7 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
         const int t0 = (int)(work - (int64_t)row * blocks_per_row) * FR;
         const int nfr = min(FR, p.frames_valid - t0);
         const S* rp = row_ptr_as<S>(p.src, row);
+        const int n_row = row_samples(p.src, row, p.n_samples);
 
         // barriers order LDS only: the previous item's output stores stay in flight instead of being waited for
         lds_barrier();   // previous work item is done with s_u / s_p (and s_tw is loaded)
@@ -110,7 +111,7 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
             // time would leave the block idle for a memory round trip per 16 taps.
             const int lo_s = t0 * p.hop + p.centre_shift - 1;                                  // incl. the pre-emphasis neighbour
             const int hi_s = (t0 + FR - 1) * p.hop + p.centre_shift + p.win_len;
-            const bool interior = nfr == FR && lo_s >= 0 && hi_s <= p.n_samples;              // block-uniform
+            const bool interior = nfr == FR && lo_s >= 0 && hi_s <= n_row;              // block-uniform
             if (interior) {
                 const S* fp = rp + base;
                 const bool pre = p.preemph != 0.f && !p.remove_dc;
@@ -138,9 +139,9 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
                 for (int j = threadIdx.x / FR; j < p.win_len; j += kRows) {
                     double v = 0.0;
                     if (f < nfr) {
-                        float x = fetch_sample(rp, base + j, p.n_samples, p.pad_mode);
+                        float x = fetch_sample(rp, base + j, n_row, p.pad_mode);
                         if (p.preemph != 0.f && !p.remove_dc) {
-                            const float prev = fetch_sample(rp, base + (j > 0 ? j - 1 : 0), p.n_samples, p.pad_mode);
+                            const float prev = fetch_sample(rp, base + (j > 0 ? j - 1 : 0), n_row, p.pad_mode);
                             x = x - p.preemph * prev;
                         }
                         v = x;
@@ -321,9 +322,10 @@ __global__ void __launch_bounds__(kThreads, 2) dftmm_kernel(const DftArgs p) {
         const int row = (int)(item / tiles_per_row);
         const int t0 = (int)(item - (int64_t)row * tiles_per_row) * 16;
         const S* rp = row_ptr_as<S>(p.src, row);
+        const int n_row = row_samples(p.src, row, p.n_samples);
         const int base = (t0 + f) * p.hop + p.centre_shift;
         const int first = t0 * p.hop + p.centre_shift;
-        const bool interior = first >= 0 && first + 15 * p.hop + L <= p.n_samples;      // wave-uniform: no padding test needed
+        const bool interior = first >= 0 && first + 15 * p.hop + L <= n_row;      // wave-uniform: no padding test needed
 
         // folded, windowed taps of this lane's pairs (float64 window x float32 sample, like the vector form)
         // (the pair index is made opaque per item: otherwise the tap offsets, masks and window values of all KS steps
@@ -341,8 +343,8 @@ __global__ void __launch_bounds__(kThreads, 2) dftmm_kernel(const DftArgs p) {
                 xh[s] = sample_value(rp[base + jh]);
                 xl[s] = sample_value(rp[base + jl]);
             } else {
-                xh[s] = fetch_sample(rp, base + jh, p.n_samples, p.pad_mode);
-                xl[s] = fetch_sample(rp, base + jl, p.n_samples, p.pad_mode);
+                xh[s] = fetch_sample(rp, base + jh, n_row, p.pad_mode);
+                xl[s] = fetch_sample(rp, base + jl, n_row, p.pad_mode);
             }
         }
         double e[KS], o[KS];
@@ -495,6 +497,17 @@ int dftgen_prepare(Plan& plan) {
     if (s.n_fft < 2 || s.n_fft > 4096 || s.win_len < 1 || s.win_off < 0 || s.win_off + s.win_len > s.n_fft) {
         set_error("dftgen: needs 2 <= n_fft <= 4096 and the window inside the DFT input");
         return MMFE_EINVAL;
+    }
+    // LDS need of the vector form (twiddles, tap array of 16 frames, power spectra when they cannot reuse the tap array):
+    // refuse here what no launch could serve.  In practice win_len close to n_fft stops fitting above n_fft of about 850.
+    if (!dftmm_supports(s)) {
+        const size_t p_bytes = (size_t)FR * (plan.n_bins + 1) * 4;
+        const bool alias = plan.n_bins <= 256 && p_bytes <= (size_t)s.win_len * FR * 8;
+        const size_t lds = (size_t)s.n_fft * 32 + (size_t)(s.win_len + 1) * FR * 8 + (alias ? 0 : p_bytes);
+        if (lds > 160 * 1024) {
+            set_error("dftgen: n_fft %d with %d window taps needs %zu bytes of LDS, a CU has %d", s.n_fft, s.win_len, lds, 160 * 1024);
+            return MMFE_EINVAL;
+        }
     }
     // half-step twiddles exp(-2 pi i n / 2N), n < 2N
     std::vector<double> tw(4 * (size_t)s.n_fft);

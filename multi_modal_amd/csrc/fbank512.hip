@@ -82,7 +82,8 @@ struct FbankArgs {
     void* out;                 // elements of out_dtype
     int out_dtype;             // MMFE_OUT_*
     int n_rows;
-    int frames_valid;      // frames computed per row (<= natural frame count, <= out_rows)
+    int n_samples;         // samples per row (ragged batches: of the longest row)
+    int frames_valid;      // frames computed per row (<= natural frame count, <= out_rows); ragged batches: upper limit
     int out_rows;          // frames per row in the output tensor
     int hop;
     int win_len;
@@ -180,6 +181,15 @@ __device__ __forceinline__ void load_frame(uint32_t (&v)[NA], const int16_t* fp,
     }
 }
 
+// Frames computed for row r (wave-uniform): the launch-wide count, or in a ragged batch what the row's own length gives.
+__device__ __forceinline__ int frames_of(const FbankArgs& p, unsigned r) {
+    if (r >= (unsigned)p.n_rows) return 0;
+    if (p.src.row_len == nullptr) return p.frames_valid;
+    const int n = row_samples(p.src, r, p.n_samples);
+    const int nat = n < p.win_len ? 0 : 1 + (n - p.win_len) / p.hop;
+    return nat < p.frames_valid ? nat : p.frames_valid;
+}
+
 // Diagnostic build only (-DMMFE_STAMPS): per-phase s_memtime shares of the main loop, printed by the launcher.
 #ifdef MMFE_STAMPS
 #define MMFE_STAMP(i)                                                                                   \
@@ -259,7 +269,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
         if (qq >= qpr) { qq -= qpr; r += 1; }
     };
 
-    const Elem* safe = row_ptr_as<Elem>(p.src, 0);      // first samples of row 0: always readable
+    const Elem* safe = static_cast<const Elem*>(p.src.base);      // the first win_len elements of the input buffer: always readable
+    int fv = frames_of(p, row);                                       // of the quad whose samples are in `nxt`
 #if MMFE_TWIDDLE_REGS == 1
     float2 twr[15];                             // W256^(b*c), c = 1..15: resident for the life of the kernel
 #pragma unroll
@@ -270,7 +281,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
     typename In::slice nxt[NA];
     {
         const int t = (int)q * 4 + fl;
-        const bool valid = row < (unsigned)p.n_rows && t < p.frames_valid;
+        const bool valid = t < fv;
         const Elem* fp = row_ptr_as<Elem>(p.src, valid ? row : 0) + (int64_t)t * p.hop;
         load_frame<NA, VEC2, EXACT>(nxt, fp, safe, valid, b, p.win_len);
     }
@@ -282,6 +293,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
         MMFE_STAMP(0);
         const int t0 = (int)q * 4;          // first frame of the quad
         const unsigned cur_row = row;
+        const int cur_fv = fv;              // frames of this row that exist
 
         float2 g[NA];
 #pragma unroll
@@ -356,7 +368,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
         advance(row, q);
         {
             const int nt = (int)q * 4 + fl;
-            const bool nvalid = row < (unsigned)p.n_rows && nt < p.frames_valid;
+            fv = frames_of(p, row);
+            const bool nvalid = nt < fv;
             const Elem* nfp = row_ptr_as<Elem>(p.src, row < (unsigned)p.n_rows ? row : 0) + (int64_t)nt * p.hop;
 #ifdef MMFE_ABL_NOLOAD
 #pragma unroll
@@ -421,7 +434,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
 #pragma unroll
             for (int r = 0; r < 4; ++r) { vab[r] = accA[r]; vab[4 + r] = NGB > 0 ? accB[r] : 1.f; }
             apply_log_affine_block(vab, p.la);
-            const int n_ok = p.frames_valid - t0;         // >= 1, wave-uniform
+            const int n_ok = cur_fv - t0;                 // wave-uniform; <= 0 for a quad past the end of a short row
             const int q4 = lane & 3, f0 = lane & ~3;      // frame slot, first filter of the lane's block
             const int64_t oidx = ((int64_t)cur_row * p.out_rows + t0 + q4) * p.n_mel + f0;
 #ifdef MMFE_ABL_NOSTORE
@@ -459,7 +472,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
             }
         } else {
             const int t = t0 + fl;
-            const bool valid = t < p.frames_valid;
+            const bool valid = t < cur_fv;
             const int64_t oidx = ((int64_t)cur_row * p.out_rows + t) * p.n_mel;
             for (int j = 0; j < p.n_pass; ++j) {
                 const int m = 16 * j + b;
@@ -733,6 +746,7 @@ int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
     a.src = src;
     a.out = out;
     a.n_rows = (int)n_rows;
+    a.n_samples = (int)std::min<int64_t>(n_samples, INT32_MAX);
     a.frames_valid = (int)frames_valid;
     a.out_rows = (int)out_frames;
     a.hop = s.hop;

@@ -60,6 +60,35 @@ __global__ void __launch_bounds__(256) fill_kernel(T* out, int64_t n_rows, int64
     }
 }
 
+// Ragged batches: one block per row (grid-stride); row r is padded from its own first missing frame on.
+struct RaggedFill {
+    const int32_t* row_len;
+    int64_t n_rows, out_frames, n_feat;
+    int n_samples, layout, frames_mode, win_len, hop, n_fft, drop_last;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) fill_ragged_kernel(T* out, const RaggedFill p, T value) {
+    for (int64_t row = blockIdx.x; row < p.n_rows; row += gridDim.x) {
+        int n = p.row_len[row];
+        n = n < 0 ? 0 : (n > p.n_samples ? p.n_samples : n);
+        int64_t first = natural_frame_count(p.frames_mode, p.win_len, p.hop, p.n_fft, n);
+        if (p.drop_last && first > 0) first -= 1;
+        if (first >= p.out_frames) continue;
+        const int64_t pad_frames = p.out_frames - first;
+        const int64_t per_row = pad_frames * p.n_feat;
+        for (int64_t rem = threadIdx.x; rem < per_row; rem += blockDim.x) {
+            int64_t o;
+            if (p.layout == MMFE_LAYOUT_TIME_MAJOR) {
+                o = (row * p.out_frames + first) * p.n_feat + rem;
+            } else {
+                const int64_t m = rem / pad_frames, t = rem - m * pad_frames;
+                o = (row * p.n_feat + m) * p.out_frames + first + t;
+            }
+            out[o] = value;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) sums_kernel(const float* x, int64_t n, double* sums) {
     double s = 0.0, q = 0.0;
     const int64_t n4 = n / 4;
@@ -122,6 +151,36 @@ int frame_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t
     return MMFE_OK;
 }
 
+// the 16-bit pattern of the rounded value, computed on the host with the kernels' round-to-nearest-even rule
+static unsigned short half_bits(float value, int out_dtype) {
+    unsigned short bits;
+    if (out_dtype == MMFE_OUT_F16) {
+        const _Float16 h = static_cast<_Float16>(value);
+        std::memcpy(&bits, &h, 2);
+    } else {
+        unsigned u;
+        std::memcpy(&u, &value, 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) u = (u | 0x400000u);
+        else u += 0x7fffu + ((u >> 16) & 1u);
+        bits = (unsigned short)(u >> 16);
+    }
+    return bits;
+}
+
+int fill_pad_rows_ragged(void* out, int out_dtype, int64_t n_rows, int64_t out_frames, int64_t n_feat, int layout, float value,
+                         const mmfe_spec& spec, const int32_t* row_len, int64_t n_samples, hipStream_t stream) {
+    if (n_rows <= 0 || out_frames <= 0 || n_feat <= 0) return MMFE_OK;
+    RaggedFill p{row_len, n_rows, out_frames, n_feat, (int)n_samples, layout, spec.frames_mode, spec.win_len, spec.hop, spec.n_fft, spec.drop_last};
+    const int grid = grid_for(n_rows, 1);
+    if (out_dtype == MMFE_OUT_F32)
+        hipLaunchKernelGGL(fill_ragged_kernel<float>, dim3(grid), dim3(256), 0, stream, static_cast<float*>(out), p, value);
+    else
+        hipLaunchKernelGGL(fill_ragged_kernel<unsigned short>, dim3(grid), dim3(256), 0, stream, static_cast<unsigned short*>(out), p,
+                           half_bits(value, out_dtype));
+    MMFE_HIP_CHECK(hipGetLastError());
+    return MMFE_OK;
+}
+
 int fill_pad_rows(void* out, int out_dtype, int64_t n_rows, int64_t out_frames, int64_t first_pad_frame, int64_t n_feat, int layout,
                   float value, hipStream_t stream) {
     if (n_rows <= 0 || first_pad_frame >= out_frames) return MMFE_OK;
@@ -130,18 +189,7 @@ int fill_pad_rows(void* out, int out_dtype, int64_t n_rows, int64_t out_frames, 
         hipLaunchKernelGGL(fill_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, stream, static_cast<float*>(out), n_rows,
                            out_frames, first_pad_frame, n_feat, layout, value);
     } else {
-        // the 16-bit pattern of the rounded value, computed on the host with the same round-to-nearest-even rule
-        unsigned short bits;
-        if (out_dtype == MMFE_OUT_F16) {
-            const _Float16 h = static_cast<_Float16>(value);
-            std::memcpy(&bits, &h, 2);
-        } else {
-            unsigned u;
-            std::memcpy(&u, &value, 4);
-            if ((u & 0x7fffffffu) > 0x7f800000u) u = (u | 0x400000u);
-            else u += 0x7fffu + ((u >> 16) & 1u);
-            bits = (unsigned short)(u >> 16);
-        }
+        const unsigned short bits = half_bits(value, out_dtype);
         hipLaunchKernelGGL(fill_kernel<unsigned short>, dim3(grid_for(total, 256)), dim3(256), 0, stream,
                            static_cast<unsigned short*>(out), n_rows, out_frames, first_pad_frame, n_feat, layout, bits);
     }

@@ -58,31 +58,10 @@ void set_error(const char* fmt, ...) {
 namespace {
 
 int natural_frames(const mmfe_spec& s, int64_t n, int64_t* frames) {
-    int64_t f = 0;
-    switch (s.frames_mode) {
-        case MMFE_FRAMES_SNIP:
-            f = n < s.win_len ? 0 : 1 + (n - s.win_len) / s.hop;
-            break;
-        case MMFE_FRAMES_CENTER: {
-            const int64_t padded = n + 2 * (int64_t)(s.n_fft / 2);
-            f = padded < s.n_fft ? 0 : 1 + (padded - s.n_fft) / s.hop;
-            break;
-        }
-        case MMFE_FRAMES_SCIPY: {
-            const int64_t ext = n + 2 * (int64_t)(s.win_len / 2);
-            if (ext < s.win_len) { f = 0; break; }
-            int64_t nadd = (-(ext - s.win_len)) % s.hop;
-            if (nadd < 0) nadd += s.hop;
-            nadd %= s.win_len;
-            f = 1 + (ext + nadd - s.win_len) / s.hop;
-            break;
-        }
-        case MMFE_FRAMES_CEIL:
-            f = n <= s.win_len ? 1 : 1 + (n - s.win_len + s.hop - 1) / s.hop;
-            break;
-        default:
-            set_error("unknown frames_mode %d", s.frames_mode);
-            return MMFE_EINVAL;
+    const int64_t f = natural_frame_count(s.frames_mode, s.win_len, s.hop, s.n_fft, n);
+    if (f < 0) {
+        set_error("unknown frames_mode %d", s.frames_mode);
+        return MMFE_EINVAL;
     }
     *frames = f;
     return MMFE_OK;
@@ -187,6 +166,16 @@ int run_common(const Plan* plan, const RowSource& src, int64_t n_rows, int64_t n
     int rc = out_shape(s, n_samples, &natural, &frames, &feat);
     if (rc) return rc;
     if (frames == 0) return MMFE_OK;
+    if (src.row_len != nullptr) {
+        if (plan->impl != IMPL_FBANK512 && plan->impl != IMPL_DFT_GENERIC && plan->impl != IMPL_RFFT400) {
+            set_error("per-row lengths are implemented for the FBANK and LOGSPEC kinds only");
+            return MMFE_EINVAL;
+        }
+        if (s.clamp_below_max > 0.f) {
+            set_error("per-row lengths are not implemented for clamp_below_max plans");
+            return MMFE_EINVAL;
+        }
+    }
     DeviceGuard guard(plan->device);
     if (!guard.ok) { set_error("cannot make device %d current", plan->device); return MMFE_EHIP; }
     hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
@@ -209,10 +198,9 @@ int run_common(const Plan* plan, const RowSource& src, int64_t n_rows, int64_t n
         default: set_error("plan has no implementation"); rc = MMFE_EINVAL;
     }
     if (rc) return rc;
-    if (natural < frames) {
-        const float v = (s.pad_value + s.out_shift) * s.out_scale;
-        rc = fill_pad_rows(out_any, s.out_dtype, n_rows, frames, natural, feat, s.layout, v, stream);
-    }
+    const float pad = (s.pad_value + s.out_shift) * s.out_scale;
+    if (src.row_len != nullptr) rc = fill_pad_rows_ragged(out_any, s.out_dtype, n_rows, frames, feat, s.layout, pad, s, src.row_len, n_samples, stream);
+    else if (natural < frames) rc = fill_pad_rows(out_any, s.out_dtype, n_rows, frames, natural, feat, s.layout, pad, stream);
     return rc;
 }
 
@@ -362,14 +350,14 @@ int mmfe_plan_destroy(mmfe_plan* plan) {
 int mmfe_run(const mmfe_plan* plan, const void* in, int64_t in_stride, int64_t n_rows, int64_t n_samples, void* out,
              void* hip_stream) {
     if (in_stride < n_samples && n_rows > 1) { set_error("in_stride (%lld) smaller than n_samples (%lld)", (long long)in_stride, (long long)n_samples); return MMFE_EINVAL; }
-    RowSource src{in, in_stride, nullptr, nullptr, nullptr};
+    RowSource src{in, in_stride, nullptr, nullptr, nullptr, nullptr};
     return run_common(reinterpret_cast<const Plan*>(plan), src, n_rows, n_samples, out, hip_stream);
 }
 
 int mmfe_run_noalloc(const mmfe_plan* plan, const void* in, int64_t in_stride, int64_t n_rows, int64_t n_samples, void* out,
                      void* hip_stream) {
     if (in_stride < n_samples && n_rows > 1) { set_error("in_stride (%lld) smaller than n_samples (%lld)", (long long)in_stride, (long long)n_samples); return MMFE_EINVAL; }
-    RowSource src{in, in_stride, nullptr, nullptr, nullptr};
+    RowSource src{in, in_stride, nullptr, nullptr, nullptr, nullptr};
     return run_common(reinterpret_cast<const Plan*>(plan), src, n_rows, n_samples, out, hip_stream, true);
 }
 
@@ -378,8 +366,24 @@ int mmfe_run_slices(const mmfe_plan* plan, const void* recs, const int64_t* rec_
     if (rec_start == nullptr || rec_index == nullptr || offsets == nullptr) { set_error("NULL slice table"); return MMFE_EINVAL; }
     const Plan* p = reinterpret_cast<const Plan*>(plan);
     if (p != nullptr && p->impl == IMPL_STFT32) { set_error("slices are not supported by the 32-point STFT kernel"); return MMFE_EINVAL; }
-    RowSource src{recs, 0, rec_start, rec_index, offsets};
+    RowSource src{recs, 0, rec_start, rec_index, offsets, nullptr};
     return run_common(p, src, n_rows, n_samples, out, hip_stream);
+}
+
+int mmfe_run_ragged(const mmfe_plan* plan, const void* in, int64_t in_stride, const int32_t* row_len, int64_t n_rows,
+                    int64_t n_samples, void* out, void* hip_stream) {
+    if (row_len == nullptr) { set_error("row_len is NULL (use mmfe_run for rows of one length)"); return MMFE_EINVAL; }
+    if (in_stride < n_samples && n_rows > 1) { set_error("in_stride (%lld) smaller than n_samples (%lld)", (long long)in_stride, (long long)n_samples); return MMFE_EINVAL; }
+    RowSource src{in, in_stride, nullptr, nullptr, nullptr, row_len};
+    return run_common(reinterpret_cast<const Plan*>(plan), src, n_rows, n_samples, out, hip_stream);
+}
+
+int mmfe_run_slices_ragged(const mmfe_plan* plan, const void* recs, const int64_t* rec_start, const int32_t* rec_index,
+                           const int64_t* offsets, const int32_t* row_len, int64_t n_rows, int64_t n_samples, void* out,
+                           void* hip_stream) {
+    if (rec_start == nullptr || rec_index == nullptr || offsets == nullptr || row_len == nullptr) { set_error("NULL slice table"); return MMFE_EINVAL; }
+    RowSource src{recs, 0, rec_start, rec_index, offsets, row_len};
+    return run_common(reinterpret_cast<const Plan*>(plan), src, n_rows, n_samples, out, hip_stream);
 }
 
 int mmfe_feature_sums(const float* x, int64_t n, double* sums, int device, void* hip_stream) {

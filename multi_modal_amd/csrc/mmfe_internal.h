@@ -29,7 +29,36 @@ struct RowSource {
     const int64_t* rec_start;  // slices only (device)
     const int32_t* rec_index;  // slices only (device)
     const int64_t* offsets;    // slices only (device)
+    const int32_t* row_len;    // ragged batches only (device): samples of row r, clamped to [0, n_samples]; NULL = every row has n_samples
 };
+
+// Samples of row r of a batch whose longest row has n_samples.
+__device__ __forceinline__ int row_samples(const RowSource& s, int64_t r, int n_samples) {
+    if (s.row_len == nullptr) return n_samples;
+    const int n = s.row_len[r];
+    return n < 0 ? 0 : (n > n_samples ? n_samples : n);
+}
+
+// Frames an n-sample row yields under mmfe_spec.frames_mode (before drop_last / out_frames).
+__host__ __device__ inline int64_t natural_frame_count(int frames_mode, int win_len, int hop, int n_fft, int64_t n) {
+    switch (frames_mode) {
+        case MMFE_FRAMES_SNIP: return n < win_len ? 0 : 1 + (n - win_len) / hop;
+        case MMFE_FRAMES_CENTER: {
+            const int64_t padded = n + 2 * (int64_t)(n_fft / 2);
+            return padded < n_fft ? 0 : 1 + (padded - n_fft) / hop;
+        }
+        case MMFE_FRAMES_SCIPY: {
+            const int64_t ext = n + 2 * (int64_t)(win_len / 2);
+            if (ext < win_len) return 0;
+            int64_t nadd = (-(ext - win_len)) % hop;
+            if (nadd < 0) nadd += hop;
+            nadd %= win_len;
+            return 1 + (ext + nadd - win_len) / hop;
+        }
+        case MMFE_FRAMES_CEIL: return n <= win_len ? 1 : 1 + (n - win_len + hop - 1) / hop;
+        default: return -1;
+    }
+}
 
 template <typename S>
 __device__ __forceinline__ const S* row_ptr_as(const RowSource& s, int64_t r) {
@@ -47,6 +76,7 @@ __device__ __forceinline__ float sample_value(int16_t v) { return (float)v * (1.
 template <typename S>
 __device__ __forceinline__ float fetch_sample(const S* row, int i, int n, int pad_mode) {
     if (i >= 0 && i < n) return sample_value(row[i]);
+    if (n <= 0) return 0.f;
     if (pad_mode == MMFE_PAD_REFLECT) {
         if (n == 1) return sample_value(row[0]);
         const int period = 2 * (n - 1);
@@ -146,6 +176,10 @@ int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64
 
 int frame_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames,
                  float* out, hipStream_t stream);
+
+// ragged batches: row r is padded from frame min(natural frames of its own length - drop_last, out_frames) on
+int fill_pad_rows_ragged(void* out, int out_dtype, int64_t n_rows, int64_t out_frames, int64_t n_feat, int layout, float value,
+                         const mmfe_spec& spec, const int32_t* row_len, int64_t n_samples, hipStream_t stream);
 
 int fill_pad_rows(void* out, int out_dtype, int64_t n_rows, int64_t out_frames, int64_t first_pad_frame, int64_t n_feat, int layout,
                   float value, hipStream_t stream);

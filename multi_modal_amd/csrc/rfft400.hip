@@ -217,9 +217,11 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
     // the samples under octet (r, o): lane holds pieces lane, lane+64, ... of 4 consecutive samples
     float4 pf[kPF];
     auto fetch = [&](unsigned r, unsigned o) {
-        const SMP* rp = row_ptr_as<SMP>(p.src, r < (unsigned)p.n_rows ? r : 0);
+        const unsigned rr = r < (unsigned)p.n_rows ? r : 0;
+        const SMP* rp = row_ptr_as<SMP>(p.src, rr);
+        const int n_row = row_samples(p.src, rr, p.n_samples);
         const int first = (int)o * 8 * hop + p.shift;
-        const bool interior = first >= 0 && first + span4 <= p.n_samples;     // wave-uniform
+        const bool interior = first >= 0 && first + span4 <= n_row;     // wave-uniform
         if (interior) {
 #pragma unroll
             for (int q = 0; q < kPF; ++q) {
@@ -233,8 +235,8 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
             for (int q = 0; q < kPF; ++q) {
                 const int i = 4 * (lane + 64 * q);
                 const int s0 = first + (i < span4 ? i : 0);
-                pf[q] = make_float4(fetch_sample(rp, s0, p.n_samples, p.pad_mode), fetch_sample(rp, s0 + 1, p.n_samples, p.pad_mode),
-                                    fetch_sample(rp, s0 + 2, p.n_samples, p.pad_mode), fetch_sample(rp, s0 + 3, p.n_samples, p.pad_mode));
+                pf[q] = make_float4(fetch_sample(rp, s0, n_row, p.pad_mode), fetch_sample(rp, s0 + 1, n_row, p.pad_mode),
+                                    fetch_sample(rp, s0 + 2, n_row, p.pad_mode), fetch_sample(rp, s0 + 3, n_row, p.pad_mode));
             }
         }
     };

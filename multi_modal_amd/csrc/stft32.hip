@@ -193,8 +193,10 @@ int stft32_prepare(Plan& plan) {
     const mmfe_spec& s = plan.spec;
     if (s.n_fft != kN || s.win_len != kN || s.win_off != 0 || s.hop < 1 || s.hop > kN || s.n_mel != 0 ||
         s.log_kind != MMFE_LOG_NONE || s.layout != MMFE_LAYOUT_FEAT_MAJOR || s.frames_mode != MMFE_FRAMES_SCIPY ||
-        s.remove_dc || s.preemph != 0.f || s.out_frames != 0 || s.out_shift != 0.f || s.out_scale != 1.f) {
-        set_error("stft32: needs n_fft == win_len == 32, 1 <= hop <= 32, scipy framing, feature-major magnitude/power output, no mel/log/affine");
+        s.remove_dc || s.preemph != 0.f || s.out_frames != 0 || s.out_shift != 0.f || s.out_scale != 1.f ||
+        s.pad_mode != MMFE_PAD_ZERO || s.clamp_below_max > 0.f || s.drop_last) {
+        set_error("stft32: needs n_fft == win_len == 32, 1 <= hop <= 32, scipy framing with zero extension, feature-major magnitude/power "
+                  "output, no mel/log/affine/clamp, natural frame count");
         return MMFE_EINVAL;
     }
     return MMFE_OK;

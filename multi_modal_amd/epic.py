@@ -47,15 +47,17 @@ def _params(window_size, step_size, resampling_rate):
 
 def log_specgram_batch(audio: torch.Tensor, window_size: int = 10, step_size: int = 5, eps: float = 1e-6,
                        resampling_rate: int = RESAMPLING_RATE, div255: bool = False,
-                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       out: Optional[torch.Tensor] = None, lengths=None) -> torch.Tensor:
     """(B, n) slices -> (B, 256, 1 + (n-1)//hop) log power spectrograms (frequency-major), one launch.
+    lengths: slices of different lengths in one batch (30 672-sample interior and 30 696-sample edge slices both give
+    256 frames, epic_kitchen.py:143-154); row r is audio[r, :lengths[r]], zero-padded at its own end like librosa does.
     div255=True folds the ToTorchFormatTensor division in, giving what the encoder consumes.
     int16 input is the pcm_s16le audio the reference extracts (recognition/dataset/extract_audio.py:9), decoded in
     the kernel as s / 32768 like librosa.load does (epic_kitchen.py:135)."""
     x, origin = to_device_rows(audio, pcm_ok=True)
     nperseg, hop = _params(window_size, step_size, resampling_rate)
     plan = _logspec_plan(x.device.index, nperseg, hop, eps, 1.0 / 255.0 if div255 else 1.0, IN_CODES[x.dtype])
-    y = run_rows(plan, x, out)
+    y = run_rows(plan, x, out, lengths)
     return y if origin.type == "cuda" else y.to(origin)
 
 
@@ -102,8 +104,8 @@ def extract_sound_features(recordings: Sequence[torch.Tensor], rec_index: Sequen
                            div255: bool = True) -> torch.Tensor:
     """Batched _extract_sound_feature + _log_specgram (+ /255): for sample i the slice of
     recordings[rec_index[i]] around (start_frame[i] + idx[i]) / fps_spec[i] is transformed straight from
-    the packed device-resident recordings (no per-slice copy).  All slices of one call must have the same
-    length (interior slices are 30 672 samples, edge slices 30 696: call once per length).
+    the packed device-resident recordings (no per-slice copy).  Interior slices (30 672 samples) and edge slices
+    (30 696) may be mixed, as a DataLoader batch of the reference mixes them: one launch serves all of them.
     Recordings that are all int16 stay 16-bit PCM on the device (half the memory) and are decoded in the kernel.
     Returns (B, 1, 256, frames)."""
     require_gpu()
@@ -118,10 +120,9 @@ def extract_sound_features(recordings: Sequence[torch.Tensor], rec_index: Sequen
     packed = torch.cat(recs) if recs else torch.empty(0, dtype=el, device=dev)
     bounds = [sound_slice_bounds(start_frame[i], idx[i], fps_spec[i], lengths[rec_index[i]], resampling_rate)
               for i in range(len(rec_index))]
-    sizes = {r - l for l, r in bounds}
-    if len(sizes) != 1:
-        raise ValueError(f"slices of different lengths in one call: {sorted(sizes)}")
-    n = sizes.pop()
+    sizes = [r - l for l, r in bounds]
+    n = max(sizes) if sizes else 0
+    ragged = len(set(sizes)) > 1
     nperseg, hop = _params(10, 5, resampling_rate)
     plan = _logspec_plan(dev.index, nperseg, hop, 1e-6, 1.0 / 255.0 if div255 else 1.0, IN_CODES[el])
     frames, feat = plan.out_shape(n)
@@ -132,9 +133,14 @@ def extract_sound_features(recordings: Sequence[torch.Tensor], rec_index: Sequen
     d_index = torch.tensor(list(rec_index), dtype=torch.int32, device=dev)
     d_off = torch.tensor([l for l, _ in bounds], dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    plan.run_slices_ptr(packed.data_ptr(), d_start.data_ptr(), d_index.data_ptr(), d_off.data_ptr(), len(bounds), n,
-                        out.data_ptr(), stream)
+    d_len = torch.tensor(sizes, dtype=torch.int32, device=dev)
+    if ragged:
+        plan.run_slices_ragged_ptr(packed.data_ptr(), d_start.data_ptr(), d_index.data_ptr(), d_off.data_ptr(), d_len.data_ptr(),
+                                   len(bounds), n, out.data_ptr(), stream)
+    else:
+        plan.run_slices_ptr(packed.data_ptr(), d_start.data_ptr(), d_index.data_ptr(), d_off.data_ptr(), len(bounds), n,
+                            out.data_ptr(), stream)
     # the index tensors must outlive the asynchronous launch on this stream
-    for t in (packed, d_start, d_index, d_off):
+    for t in (packed, d_start, d_index, d_off, d_len):
         t.record_stream(torch.cuda.current_stream(dev))
     return out

@@ -77,11 +77,13 @@ def fbank_batch(waveforms: torch.Tensor, *, out_frames: int = 0, pad_value: floa
                 frame_length: float = 25.0, frame_shift: float = 10.0, high_freq: float = 0.0, low_freq: float = 20.0,
                 num_mel_bins: int = 23, preemphasis_coefficient: float = 0.97, remove_dc_offset: bool = True,
                 round_to_power_of_two: bool = True, sample_frequency: float = 16000.0, use_log_fbank: bool = True,
-                window_type: str = "povey", dtype: torch.dtype = torch.float32) -> torch.Tensor:
+                window_type: str = "povey", dtype: torch.dtype = torch.float32, lengths=None) -> torch.Tensor:
     """Batched form: (B, n) -> (B, m, num_mel_bins), one launch for the whole batch.  With out_frames > 0
     each clip is cut / padded (pad_value) to out_frames frames and (x + out_shift) * out_scale is applied.
     dtype=torch.float16 / torch.bfloat16 stores the float32 result rounded to nearest even (what a consumer
     under autocast would cast it to); only the power-of-two 512-point path implements it.
+    lengths (one integer per clip, <= n): a ragged batch, clip r is waveforms[r, :lengths[r]] (the tensor is padded to the longest
+    clip); frames a shorter clip does not have carry pad_value, as if out_frames had padded that clip alone.
     An int16 tensor is taken as 16-bit PCM (value s / 32768, what torchaudio.load makes of the reference's FLAC
     files, vggsound.py:66) and decoded inside the kernel: same bits out as for the decoded float32 waveform."""
     if dtype not in OUT_CODES:
@@ -94,7 +96,7 @@ def fbank_batch(waveforms: torch.Tensor, *, out_frames: int = 0, pad_value: floa
                        low_freq=low_freq, high_freq=high_freq, use_log_fbank=use_log_fbank, out_frames=out_frames,
                        pad_value=pad_value, out_shift=out_shift, out_scale=out_scale, out_dtype=OUT_CODES[dtype],
                        in_dtype=IN_CODES[x.dtype])
-    y = run_rows(plan, x, out)
+    y = run_rows(plan, x, out, lengths)
     return y if origin.type == "cuda" else y.to(origin)
 
 

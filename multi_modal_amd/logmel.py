@@ -18,8 +18,10 @@ from . import melbank
 from .plans import IN_CODES, cached_plan, run_rows, to_device_rows
 
 
-def _plan(device: int, n_fft: int, hop: int, n_mels: int, sr: int, f64: bool, in_dtype: int = N.IN_F32) -> N.Plan:
-    key = ("logmel", n_fft, hop, n_mels, sr, f64, int(in_dtype))
+def _plan(device: int, n_fft: int, hop: int, n_mels: int, sr: int, f64: bool, in_dtype: int = N.IN_F32, stream: int = 0) -> N.Plan:
+    # A plan with clamp_below_max owns the per-row extremes its two passes exchange, so two calls on one plan must not
+    # overlap on the device: the cache keeps one plan per HIP stream (calls on one stream are ordered).
+    key = ("logmel", n_fft, hop, n_mels, sr, f64, int(in_dtype), int(stream))
 
     def build(dev: int) -> N.Plan:
         fb = melbank.slaney_mel_filters(1 + n_fft // 2, n_mels, sr)
@@ -45,6 +47,7 @@ def log_mel_spectrogram(waveforms: torch.Tensor, n_fft: int = 400, hop_length: i
     if precision not in ("float32", "float64"):
         raise ValueError("precision must be 'float32' or 'float64'")
     x, origin = to_device_rows(waveforms, pcm_ok=True)
-    plan = _plan(x.device.index, n_fft, hop_length, n_mels, sampling_rate, precision == "float64", IN_CODES[x.dtype])
+    plan = _plan(x.device.index, n_fft, hop_length, n_mels, sampling_rate, precision == "float64", IN_CODES[x.dtype],
+                 torch.cuda.current_stream(x.device).cuda_stream)
     y = run_rows(plan, x, out)
     return y if origin.type == "cuda" else y.to(origin)

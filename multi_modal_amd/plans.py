@@ -71,9 +71,23 @@ def to_device_rows(x: torch.Tensor, pcm_ok: bool = False) -> Tuple[torch.Tensor,
     return x, origin
 
 
-def run_rows(plan: N.Plan, x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+def row_lengths(lengths, rows: int, n: int, device: torch.device) -> torch.Tensor:
+    """Per-row sample counts of a ragged batch as the int32 device tensor mmfe_run_ragged reads."""
+    t = torch.as_tensor(lengths)
+    if t.dim() != 1 or t.shape[0] != rows:
+        raise ValueError(f"lengths must hold one entry per row ({rows}), got {tuple(t.shape)}")
+    if t.is_floating_point():
+        raise TypeError("lengths must be integers")
+    if not t.is_cuda and rows > 0 and (int(t.min()) < 0 or int(t.max()) > n):
+        raise ValueError(f"lengths must lie in [0, {n}] (the width of the batch tensor)")
+    return t.to(device=device, dtype=torch.int32).contiguous()
+
+
+def run_rows(plan: N.Plan, x: torch.Tensor, out: torch.Tensor = None, lengths=None) -> torch.Tensor:
     """Run `plan` over the rows of a CUDA tensor (rows, n).  Returns (rows, frames, feat) for time-major
-    plans and (rows, feat, frames) for feature-major ones.  Asynchronous on the current stream."""
+    plans and (rows, feat, frames) for feature-major ones.  Asynchronous on the current stream.
+    `lengths` (one integer per row, <= n) makes the batch ragged: row r is transformed as if it were x[r, :lengths[r]]
+    passed alone, in the same single launch; frames it does not have are filled with the plan's pad value."""
     assert x.is_cuda and x.dim() == 2 and x.dtype == IN_DTYPES[plan.spec.in_dtype]
     rows, n = x.shape
     frames, feat = plan.out_shape(n)
@@ -93,5 +107,10 @@ def run_rows(plan: N.Plan, x: torch.Tensor, out: torch.Tensor = None) -> torch.T
     _last_kernel = plan.kernel
     stream = torch.cuda.current_stream(x.device).cuda_stream
     stride = x.stride(0) if rows > 1 else max(x.stride(0), n)
-    plan.run_ptr(x.data_ptr(), stride, rows, n, out.data_ptr(), stream)
+    if lengths is None:
+        plan.run_ptr(x.data_ptr(), stride, rows, n, out.data_ptr(), stream)
+    else:
+        d_len = row_lengths(lengths, rows, n, x.device)
+        plan.run_ragged_ptr(x.data_ptr(), stride, d_len.data_ptr(), rows, n, out.data_ptr(), stream)
+        d_len.record_stream(torch.cuda.current_stream(x.device))      # must outlive the asynchronous launch
     return out

@@ -27,11 +27,13 @@ class RunningNorm:
 
     def update(self, features: torch.Tensor) -> None:
         x = features
-        if not x.is_cuda:
+        if x.device != self.device:          # the sums live on self.device: a kernel on another GPU must not add into them
             x = x.to(self.device)
         x = x.to(torch.float32).contiguous()
         if x.numel() == 0:
             return
+        if x.data_ptr() % 16 != 0:           # a contiguous view at an odd storage offset: the kernel reads 16-byte words
+            x = x.clone()
         stream = torch.cuda.current_stream(x.device).cuda_stream
         N.feature_sums_ptr(x.data_ptr(), x.numel(), self.sums.data_ptr(), x.device.index, stream)
         self.count += x.numel()

@@ -20,8 +20,10 @@ _KW = dict(sample_frequency=SAMPLE_RATE, window_type="hanning", num_mel_bins=NUM
 
 
 def preprocessing_audio_batch(audio: torch.Tensor, out: Optional[torch.Tensor] = None,
-                              dtype: torch.dtype = torch.float32) -> torch.Tensor:
+                              dtype: torch.dtype = torch.float32, lengths=None) -> torch.Tensor:
     """(B, n) or (B, 1, n) waveforms -> (B, 384, 128) normalised log-mel, one launch per batch.
+    lengths: clips of different lengths in one batch (each row of `audio` padded to the longest); every clip is padded /
+    cut to 384 frames on its own, as vggsound.py:48-56 does per sample.
     dtype=torch.float16 hands the encoder the tensor its @autocast() would cast to
     (classification/vggsound/models/vit_model.py:388), without a float32 round trip through HBM.
     This is the call that replaces `batch[k].to(device)` of a collated spectrogram batch
@@ -32,7 +34,7 @@ def preprocessing_audio_batch(audio: torch.Tensor, out: Optional[torch.Tensor] =
         audio = audio[:, 0, :]
     if audio.dim() != 2:
         raise ValueError(f"expected (B, n) or (B, 1, n), got {tuple(audio.shape)}")
-    return fbank_batch(audio, out=out, dtype=dtype, **_KW)
+    return fbank_batch(audio, out=out, dtype=dtype, lengths=lengths, **_KW)
 
 
 def preprocessing_audio(audio: torch.Tensor) -> torch.Tensor:

@@ -54,6 +54,9 @@ def har():
 
 
 def frame_signal():
+    # Only the `frame_signal` function definition of the reference file is compiled and run (its module import needs the
+    # absent torchvision).  That definition was read before it was run here: it is index arithmetic and torch tensor
+    # operations (torch.zeros / torch.cat / arange / indexing / multiply), with no imports, I/O or calls beyond torch and math.
     src = open(os.path.join(REF, "classification/vggsound/utils/transforms.py")).read()
     fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "frame_signal"][0]
     ns = {"torch": torch, "math": math}

@@ -228,6 +228,112 @@ def test_epic_batch_div255_and_slices(mm, O):
         assert np.abs(got[i] - ref).max() <= 1e-4 / 255 + 1e-7
 
 
+def test_epic_mixed_slice_lengths_one_launch(mm, O):
+    """A batch that mixes interior (30 672 +- 1 samples) and edge (30 696) slices, as a DataLoader batch of the reference
+    does (epic_kitchen.py:143-154): ONE call, each row equal to its own per-slice oracle within 1e-4 / 255."""
+    recs = [synth("noise0.1", 24000 * 5, 11), synth("uniform", 24000 * 4 + 333, 12), synth("quiet", 24000 * 3, 13)]
+    rec_index = [0, 0, 1, 1, 2, 2, 0, 1]
+    start_frame = [0, 100, 30, 10 ** 6, 60, 0, 170, 95]
+    idx = [0, 3, 7, 0, 2, 0, 1, 4]
+    fps = [60.0, 60.0, 50.0, 50.0, 60.0, 60.0, 60.0, 50.0]
+    bounds = [O.sound_slice_bounds(start_frame[i], idx[i], fps[i], len(recs[rec_index[i]])) for i in range(len(idx))]
+    sizes = {r - l for l, r in bounds}
+    assert 30696 in sizes and len(sizes) >= 2
+    ref = np.stack([O.spec_to_tensor(O.log_specgram(recs[rec_index[i]][l:r])).numpy() for i, (l, r) in enumerate(bounds)])
+    got = mm.epic.extract_sound_features([torch.from_numpy(r) for r in recs], rec_index, start_frame, idx, fps).cpu().numpy()
+    assert got.shape == ref.shape == (len(idx), 1, 256, 256)
+    assert np.abs(got - ref).max() <= 1e-4 / 255 + 1e-7
+    # the same through the strided ragged entry: rows padded to the longest slice, garbage in the padding
+    n = max(sizes)
+    rows = np.full((len(idx), n), 7.0, np.float32)
+    for i, (l, r) in enumerate(bounds):
+        rows[i, : r - l] = recs[rec_index[i]][l:r]
+    got2 = mm.log_specgram_batch(torch.from_numpy(rows).cuda(), div255=True, lengths=[r - l for l, r in bounds]).cpu().numpy()
+    assert np.array_equal(got2[:, None], got)
+    # 16-bit PCM recordings, mixed lengths
+    pcm = [torch.from_numpy(np.clip(np.round(r.astype(np.float64) * 32768), -32768, 32767).astype(np.int16)) for r in recs]
+    dec = [p.to(torch.float32) / 32768 for p in pcm]
+    a = mm.epic.extract_sound_features(pcm, rec_index, start_frame, idx, fps)
+    b = mm.epic.extract_sound_features(dec, rec_index, start_frame, idx, fps)
+    assert torch.equal(a, b)
+
+
+def test_vggsound_ragged_batch_one_launch(mm, O):
+    """Clips of different lengths in one batch tensor (padded with garbage to the longest): every clip's features equal
+    those of the clip passed alone, bit for bit, through both load variants and the C ABI's mmfe_run_ragged directly."""
+    lens = [160000, 399, 400, 401, 12345, 153600, 0, 80000, 159999]
+    n = max(lens)
+    rows = np.full((len(lens), n), 0.9, np.float32)
+    clips = [synth("noise0.1", max(l, 1), 50 + i)[:l] for i, l in enumerate(lens)]
+    for i, c in enumerate(clips):
+        rows[i, : len(c)] = c
+    x = torch.from_numpy(rows).cuda()
+    got = mm.preprocessing_audio_batch(x, lengths=lens)
+    assert mm.plans.last_kernel() == "fbank512" and tuple(got.shape) == (len(lens), 384, 128)
+    for i, c in enumerate(clips):
+        if len(c) < 400:
+            assert torch.all(got[i] == got[1, 0, 0]) and abs(float(got[i, 0, 0]) - 5.1991 / 4.4049) < 1e-6
+            continue
+        # the clip alone, in a buffer of even row stride so that it takes the same load variant of the kernel as the
+        # batch (the variants round the pre-emphasis differently in the last bit: equal to tolerance, not to the bit)
+        buf = torch.zeros(1, len(c) + (len(c) & 1), device="cuda")
+        buf[0, : len(c)] = torch.from_numpy(c).cuda()
+        alone = mm.preprocessing_audio_batch(buf[:, : len(c)])[0]
+        assert torch.equal(got[i], alone), i
+        ref = O.preprocessing_audio(torch.from_numpy(c)[None]).numpy()
+        assert np.abs(got[i].cpu().numpy() - ref).max() <= 5e-4
+    # odd row stride -> the scalar-load variant; lengths given as a device tensor
+    xo = torch.empty(len(lens), n + 1, device="cuda")[:, :n]
+    xo.copy_(x)
+    got_o = mm.preprocessing_audio_batch(xo, lengths=torch.tensor(lens, device="cuda"))
+    assert float((got_o - got).abs().max()) <= 5e-4
+    i = lens.index(159999)                      # an odd-length clip alone has an odd row stride: the same (scalar-load) variant
+    assert torch.equal(got_o[i], mm.preprocessing_audio_batch(torch.from_numpy(clips[i])[None].cuda())[0])
+    # bfloat16 output, ragged
+    got_h = mm.preprocessing_audio_batch(x, lengths=lens, dtype=torch.bfloat16)
+    assert torch.equal(got_h, got.to(torch.bfloat16))
+    # lengths beyond the tensor are refused on the host when they are host data
+    with pytest.raises(ValueError):
+        mm.preprocessing_audio_batch(x, lengths=[n + 1] * len(lens))
+    # other kinds say so instead of ignoring the lengths
+    from multi_modal_amd import _native as N
+    with pytest.raises(N.MmfeError, match="per-row lengths"):
+        mm.plans.run_rows(mm.har._stft_plan(0, 32, 28), torch.zeros(4, 64, device="cuda"), lengths=[64, 64, 32, 64])
+
+
+def test_logmel_ragged_rows(mm, O):
+    """The n_fft 400 kernel (reflect padding at each row's own end) and the any-length kernel on ragged rows; the
+    long-utterance configuration with its per-row clamp refuses them."""
+    from multi_modal_amd import _native as N
+    from multi_modal_amd import melbank
+    lens = [48000, 16000, 401, 47999, 32160]
+    n = max(lens)
+    rows = np.full((len(lens), n), -0.7, np.float32)
+    clips = [synth("noise0.1", l, 70 + i) for i, l in enumerate(lens)]
+    for i, c in enumerate(clips):
+        rows[i, : len(c)] = c
+    fb = melbank.slaney_mel_filters(201, 80, 16000)
+    bs, bl, bw = melbank.dense_to_bands(fb.astype(np.float32))
+    for f64 in (False, True):
+        spec = N.make_spec(kind=N.KIND_LOGSPEC, n_fft=400, win_len=400, hop=160, pad_mode=N.PAD_REFLECT, frames_mode=N.FRAMES_CENTER,
+                           n_mel=80, power=2, log_kind=N.LOG_LOG10_MAX, log_floor=1e-10, drop_last=1, layout=N.LAYOUT_FEAT_MAJOR,
+                           pad_value=-3.0, window_f64=1 if f64 else 0)
+        plan = N.Plan(spec, melbank.periodic_hann(400), bs, bl, bw, device=0)
+        assert plan.kernel == ("dftgen" if f64 else "rfft400")
+        x = torch.from_numpy(rows).cuda()
+        got = mm.plans.run_rows(plan, x, lengths=lens)
+        frames_max = n // 160
+        assert tuple(got.shape) == (len(lens), 80, frames_max)
+        for i, c in enumerate(clips):
+            alone = mm.plans.run_rows(plan, torch.from_numpy(c)[None].cuda())[0]
+            fr = alone.shape[1]
+            assert fr == len(c) // 160
+            assert torch.equal(got[i, :, :fr], alone), (f64, i)
+            assert torch.all(got[i, :, fr:] == -3.0)
+    with pytest.raises(N.MmfeError, match="clamp_below_max"):
+        mm.plans.run_rows(mm.logmel._plan(0, 400, 160, 80, 16000, False), torch.zeros(2, 16000, device="cuda"), lengths=[16000, 8000])
+
+
 def test_har_short_input_rejected(mm):
     for shape in [(1, 31), (2, 4)]:
         with pytest.raises(ValueError):
@@ -575,6 +681,68 @@ def test_plans_shared_between_threads_and_streams(mm):
         assert torch.equal(got[t][0], want[t][0]) and torch.equal(got[t][1], want[t][1])
 
 
+def test_clamp_plans_are_per_stream(mm):
+    """The long-utterance log-mel (clamp_below_max: two passes that exchange per-row extremes through a scratch the plan
+    owns) called from two host threads on two streams: the wrapper keeps one plan per stream, so the calls may overlap
+    on the device and still give the bits of the serial calls."""
+    import threading
+    g = torch.Generator(device="cuda").manual_seed(11)
+    xs = [torch.randn(64, 160000, device="cuda", generator=g) * torch.logspace(-3, 0, 64, device="cuda")[:, None] for _ in range(2)]
+    want = [mm.logmel.log_mel_spectrogram(x) for x in xs]
+    torch.cuda.synchronize()
+    got, errs, plans = [None, None], [], [None, None]
+
+    def work(t):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(40):
+                    y = mm.logmel.log_mel_spectrogram(xs[t])
+                plans[t] = mm.logmel._plan(0, 400, 160, 80, 16000, False, stream=s.cuda_stream)
+                s.synchronize()
+            got[t] = y
+        except Exception as e:      # surfaced by the assert below
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errs, errs
+    assert plans[0] is not plans[1]
+    for t in range(2):
+        assert torch.equal(got[t], want[t])
+
+
+def test_plan_creation_rejects_what_no_launch_could_serve(mm):
+    """Specs that used to be accepted and then failed or were silently computed differently at run time."""
+    from multi_modal_amd import _native as N
+    from multi_modal_amd import melbank
+    # a 50 ms kaldi window at 16 kHz (800 taps, n_fft 1024) needs more LDS than a CU has: refused at plan creation
+    with pytest.raises(N.MmfeError, match="LDS"):
+        mm.fbank(torch.zeros(1, 16000, device="cuda"), frame_length=50.0, sample_frequency=16000)
+    # the 32-point STFT kernel implements zero extension without clamp / dropped frame only
+    win = melbank.periodic_hann(32)
+    for bad in (dict(pad_mode=N.PAD_REFLECT), dict(clamp_below_max=1.0), dict(drop_last=1)):
+        kw = dict(kind=N.KIND_STFT_MAG, n_fft=32, win_len=32, hop=4, pad_mode=N.PAD_ZERO, frames_mode=N.FRAMES_SCIPY, power=1,
+                  spec_scale=1.0 / 16.0, layout=N.LAYOUT_FEAT_MAJOR, window_f64=1)
+        kw.update(bad)
+        with pytest.raises(N.MmfeError, match="stft32"):
+            N.Plan(N.make_spec(**kw), win, device=0)
+
+
+def test_cal_norm_odd_offsets_and_devices(mm):
+    """cal_norm on a contiguous view that starts 4 bytes into its storage (not 16-byte aligned) and on a CPU tensor."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    f = torch.randn(100003, device="cuda", generator=g)
+    v = f[1:]
+    mean, std = mm.stats.cal_norm(v)
+    assert abs(mean - float(v.double().mean())) < 1e-9 and abs(std - float(v.double().std(unbiased=False))) < 1e-9
+    mean_c, std_c = mm.stats.cal_norm(v.cpu())
+    assert abs(mean_c - mean) < 1e-12 and abs(std_c - std) < 1e-12      # float64 atomics: the order of the adds varies
+
+
 def _pcm(kind, n, seed):
     """A synthetic waveform quantised the way a 16-bit FLAC / pcm_s16le file holds it."""
     return np.clip(np.round(synth(kind, n, seed).astype(np.float64) * 32768.0), -32768, 32767).astype(np.int16)
@@ -733,12 +901,12 @@ def test_runs_are_capturable_in_a_hip_graph(mm):
     ]
     for fn, x, shape in cases:
         out = torch.empty(shape, device="cuda")
-        fn(x, out)                                   # warm-up: plan creation and per-kernel launch attributes happen here
-        torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            fn(x, out)                               # warm-up ON THE CAPTURE STREAM: plan creation (the log-mel wrapper keeps one
+            side.synchronize()                       # plan per stream) and per-kernel launch attributes happen here
             with torch.cuda.graph(graph, stream=side):
                 fn(x, out)
         torch.cuda.current_stream().wait_stream(side)
