@@ -182,9 +182,10 @@ __device__ __forceinline__ void load_frame(uint32_t (&v)[NA], const int16_t* fp,
 }
 
 // Frames computed for row r (wave-uniform): the launch-wide count, or in a ragged batch what the row's own length gives.
+template <bool RAGGED>
 __device__ __forceinline__ int frames_of(const FbankArgs& p, unsigned r) {
+    if (!RAGGED) return p.frames_valid;
     if (r >= (unsigned)p.n_rows) return 0;
-    if (p.src.row_len == nullptr) return p.frames_valid;
     const int n = row_samples(p.src, r, p.n_samples);
     const int nat = n < p.win_len ? 0 : 1 + (n - p.win_len) / p.hop;
     return nat < p.frames_valid ? nat : p.frames_valid;
@@ -205,7 +206,8 @@ __device__ __forceinline__ int frames_of(const FbankArgs& p, unsigned r) {
 #define MMFE_STAMP(i) do { } while (0)
 #endif
 
-template <bool PCM, int NA /* ceil(win_len/32) */, bool VEC2, bool EXACT, int NGA, int NGB /* groups of 4 bins per mel set; NGA == 0: VALU mel */>
+template <bool PCM, int NA /* ceil(win_len/32) */, bool VEC2, bool EXACT, int NGA, int NGB /* groups of 4 bins per mel set; NGA == 0: VALU mel */,
+          bool RAGGED /* per-row lengths (FbankArgs::src.row_len) */>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_SIMD) fbank512_kernel(const FbankArgs p) {
     typedef Input<PCM> In;
     typedef typename In::elem Elem;
@@ -269,8 +271,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
         if (qq >= qpr) { qq -= qpr; r += 1; }
     };
 
-    const Elem* safe = static_cast<const Elem*>(p.src.base);      // the first win_len elements of the input buffer: always readable
-    int fv = frames_of(p, row);                                       // of the quad whose samples are in `nxt`
+    // where masked lanes read: the first win_len samples of row 0, or (ragged batches: row 0 may be shorter than a window) of the buffer
+    const Elem* safe = RAGGED ? static_cast<const Elem*>(p.src.base) : row_ptr_as<Elem>(p.src, 0);
+    int fv = frames_of<RAGGED>(p, row);                                       // of the quad whose samples are in `nxt`
 #if MMFE_TWIDDLE_REGS == 1
     float2 twr[15];                             // W256^(b*c), c = 1..15: resident for the life of the kernel
 #pragma unroll
@@ -281,7 +284,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
     typename In::slice nxt[NA];
     {
         const int t = (int)q * 4 + fl;
-        const bool valid = t < fv;
+        const bool valid = row < (unsigned)p.n_rows && t < fv;
         const Elem* fp = row_ptr_as<Elem>(p.src, valid ? row : 0) + (int64_t)t * p.hop;
         load_frame<NA, VEC2, EXACT>(nxt, fp, safe, valid, b, p.win_len);
     }
@@ -368,8 +371,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
         advance(row, q);
         {
             const int nt = (int)q * 4 + fl;
-            fv = frames_of(p, row);
-            const bool nvalid = nt < fv;
+            fv = frames_of<RAGGED>(p, row);
+            const bool nvalid = row < (unsigned)p.n_rows && nt < fv;
             const Elem* nfp = row_ptr_as<Elem>(p.src, row < (unsigned)p.n_rows ? row : 0) + (int64_t)nt * p.hop;
 #ifdef MMFE_ABL_NOLOAD
 #pragma unroll
@@ -501,10 +504,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
 }
 
 // `want` blocks cover the batch once; the grid is persistent, at most `per_cu` blocks on each CU of the current device.
-template <bool PCM, int NA, bool VEC2, bool EXACT, int NGA, int NGB>
+template <bool PCM, int NA, bool VEC2, bool EXACT, int NGA, int NGB, bool RAGGED>
 int launch_variant(const FbankArgs& args, int64_t want, int per_cu, size_t lds, hipStream_t stream) {
     int resident = 0, cus = 0;      // raises the variant's dynamic-LDS limit on this device (once) and returns the cached CU count
-    const int prc = kernel_prepare(reinterpret_cast<const void*>(&fbank512_kernel<PCM, NA, VEC2, EXACT, NGA, NGB>), 64 * kWavesPerBlock, lds,
+    const int prc = kernel_prepare(reinterpret_cast<const void*>(&fbank512_kernel<PCM, NA, VEC2, EXACT, NGA, NGB, RAGGED>), 64 * kWavesPerBlock, lds,
                                    &resident, &cus);
     if (prc) return prc;
     const int grid = (int)std::min<int64_t>(want, (int64_t)cus * per_cu);
@@ -513,7 +516,7 @@ int launch_variant(const FbankArgs& args, int64_t want, int per_cu, size_t lds, 
     const size_t n_st = (size_t)grid * kWavesPerBlock * 8;
     MMFE_HIP_CHECK(hipMalloc((void**)&targs.stamps, n_st * 8));
     MMFE_HIP_CHECK(hipMemset(targs.stamps, 0, n_st * 8));
-    hipLaunchKernelGGL((fbank512_kernel<PCM, NA, VEC2, EXACT, NGA, NGB>), dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, targs);
+    hipLaunchKernelGGL((fbank512_kernel<PCM, NA, VEC2, EXACT, NGA, NGB, RAGGED>), dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, targs);
     MMFE_HIP_CHECK(hipDeviceSynchronize());
     std::vector<unsigned long long> h(n_st);
     MMFE_HIP_CHECK(hipMemcpy(h.data(), targs.stamps, n_st * 8, hipMemcpyDeviceToHost));
@@ -529,7 +532,7 @@ int launch_variant(const FbankArgs& args, int64_t want, int per_cu, size_t lds, 
     }
     return MMFE_OK;
 #else
-    hipLaunchKernelGGL((fbank512_kernel<PCM, NA, VEC2, EXACT, NGA, NGB>), dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, args);
+    hipLaunchKernelGGL((fbank512_kernel<PCM, NA, VEC2, EXACT, NGA, NGB, RAGGED>), dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, args);
     MMFE_HIP_CHECK(hipGetLastError());
     return MMFE_OK;
 #endif
@@ -789,16 +792,24 @@ int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
     else vec2 = false;   // slice offsets are data: take the scalar-load variant
     const int na = (s.win_len + 31) / 32;
     const int nga = plan.mel4_nga, ngb = plan.mel4_ngb;
-#define MMFE_FBANK_DISPATCH(NGA_, NGB_)                                                                         \
-    if (nga == NGA_ && ngb == NGB_) {                                                                           \
-        if (pcm) {                                                                                              \
-            if (na == 13 && vec2) return launch_variant<true, 13, true, true, NGA_, NGB_>(a, want, per_cu, lds, stream); \
-            return vec2 ? launch_variant<true, 16, true, false, NGA_, NGB_>(a, want, per_cu, lds, stream)               \
-                        : launch_variant<true, 16, false, false, NGA_, NGB_>(a, want, per_cu, lds, stream);             \
-        }                                                                                                       \
-        if (na == 13 && vec2) return launch_variant<false, 13, true, true, NGA_, NGB_>(a, want, per_cu, lds, stream);   \
-        return vec2 ? launch_variant<false, 16, true, false, NGA_, NGB_>(a, want, per_cu, lds, stream)                  \
-                    : launch_variant<false, 16, false, false, NGA_, NGB_>(a, want, per_cu, lds, stream);                \
+    const bool ragged = src.row_len != nullptr;
+#define MMFE_FBANK_DISPATCH(NGA_, NGB_)                                                                                  \
+    if (nga == NGA_ && ngb == NGB_) {                                                                                    \
+        if (ragged) {      /* ragged batches: the forms without a compile-time window length */                          \
+            if (pcm) return vec2 ? launch_variant<true, 16, true, false, NGA_, NGB_, true>(a, want, per_cu, lds, stream)  \
+                                 : launch_variant<true, 16, false, false, NGA_, NGB_, true>(a, want, per_cu, lds, stream); \
+            if (na == 13 && vec2) return launch_variant<false, 13, true, true, NGA_, NGB_, true>(a, want, per_cu, lds, stream); \
+            return vec2 ? launch_variant<false, 16, true, false, NGA_, NGB_, true>(a, want, per_cu, lds, stream)         \
+                        : launch_variant<false, 16, false, false, NGA_, NGB_, true>(a, want, per_cu, lds, stream);       \
+        }                                                                                                                \
+        if (pcm) {                                                                                                       \
+            if (na == 13 && vec2) return launch_variant<true, 13, true, true, NGA_, NGB_, false>(a, want, per_cu, lds, stream); \
+            return vec2 ? launch_variant<true, 16, true, false, NGA_, NGB_, false>(a, want, per_cu, lds, stream)         \
+                        : launch_variant<true, 16, false, false, NGA_, NGB_, false>(a, want, per_cu, lds, stream);       \
+        }                                                                                                                \
+        if (na == 13 && vec2) return launch_variant<false, 13, true, true, NGA_, NGB_, false>(a, want, per_cu, lds, stream); \
+        return vec2 ? launch_variant<false, 16, true, false, NGA_, NGB_, false>(a, want, per_cu, lds, stream)            \
+                    : launch_variant<false, 16, false, false, NGA_, NGB_, false>(a, want, per_cu, lds, stream);          \
     }
     MMFE_FBANK_DISPATCH(2, 7)
     MMFE_FBANK_DISPATCH(3, 8)
