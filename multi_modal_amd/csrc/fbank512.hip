@@ -65,6 +65,9 @@ typedef float mmfe_f32x4 __attribute__((ext_vector_type(4)));
 #define MMFE_TWIDDLE_REGS 2   // where the first-half twiddles W256^(b*c) live.  2: a [c][b] table in LDS (the 16 lanes of a frame read 128
 #endif                        // contiguous bytes, conflict-free), which frees 30 VGPRs and lets a fourth wave per SIMD in: 2.7 % faster than
                               // 1: 30 VGPRs per lane (3 waves per SIMD);  0: the W256 table in LDS indexed b*c (bank conflicts, slowest)
+#ifndef MMFE_Z_PARK
+#define MMFE_Z_PARK 1         // how the pairs (k, 256-k) of the recombination meet.  0: all of Z is parked in LDS and both members are read
+#endif                        // back; 1: Z[k] stays in the lane's registers (lane b owns k = b + 16 i), only the upper half of Z is parked
 #ifndef MMFE_MEL_ACC_A
 #define MMFE_MEL_ACC_A 1
 #endif
@@ -359,8 +362,11 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
         // ---- second half: lane c = b now owns Z[c + 16 d]; park Z in natural order --------------
         MMFE_STAMP(3);
         fft16(u);
+        // Lane b recombines k = b + 16 i, i < 8: Z[k] is its own register i, and the partner Z[256 - k] is register 15 - i of lane
+        // 16 - b (register 16 - i of lane 0 itself when b = 0), i.e. always one of the upper eight registers of some lane:
+        // only those go through LDS.  The one exception, Z[256 - 0] = Z[0], is lane 0's own register 0.
 #pragma unroll
-        for (int d = 0; d < 16; ++d) fbuf[b + 16 * d] = u[fft16_pos(d)];
+        for (int d = MMFE_Z_PARK ? 8 : 0; d < 16; ++d) fbuf[b + 16 * d] = u[fft16_pos(d)];
         // bin 128 pairs with itself: X[128] = 2*conj(Z[128]) (window pre-halved), and Z[128] is lane 0's d = 8
         const float p128 = 4.0f * (u[fft16_pos(8)].x * u[fft16_pos(8)].x + u[fft16_pos(8)].y * u[fft16_pos(8)].y);
         wave_lds_fence();
@@ -386,8 +392,14 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int k = b + 16 * i;
+#if MMFE_Z_PARK
+            const float2 zk = u[fft16_pos(i)];
+            float2 zp = fbuf[(256 - k) & 255];
+            if (i == 0) zp = make_float2(b == 0 ? zk.x : zp.x, b == 0 ? zk.y : zp.y);
+#else
             const float2 zk = fbuf[k];
             const float2 zp = fbuf[(256 - k) & 255];
+#endif
             const float2 tw = s_tw_post[k];
             const float2 E = make_float2(zk.x + zp.x, zk.y - zp.y);
             const float2 D = make_float2(zk.x - zp.x, zk.y + zp.y);
