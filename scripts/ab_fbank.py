@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
-"""A/B timing of several builds of libmmfe.so on the VGGSound log-mel configuration, in ONE process with
+"""A/B timing of several builds of libmmfe.so on one benchmark configuration, in ONE process with
 interleaved rounds (separate processes add variance that looks like a kernel property).
 
-    python scripts/ab_fbank.py [--batch 4096] [--rounds 6] [--launches 20] name=path.so [name=path.so ...]
+    python scripts/ab_fbank.py [--config vgg|logmel|har] [--batch N] [--rounds 6] [--launches 20] name=path.so [name=path.so ...]
+
+  vgg     VGGSound log-mel, 4096 clips of 160 000 samples (kernel fbank512)
+  logmel  long-utterance log-mel, 1024 utterances of 480 000 samples (kernel rfft400 + clamp pass)
+  har     IMU STFT, 262 144 windows of 6 x 192 samples (kernel stft32)
 
 Every build gets its own plan; round r times `launches` launches of every build in turn with HIP events.
 Prints per build: median / min of the per-launch times, the median of the per-round medians, and the maximum
@@ -23,10 +27,16 @@ from multi_modal_amd import _native as N          # noqa: E402
 from multi_modal_amd import kaldi, plans, vggsound  # noqa: E402
 
 
-def build_plan(path, device, in_dtype=N.IN_F32):
-    """The VGGSound plan of kaldi._fbank_plan, created through the library at `path`."""
+def build_plan(path, device, in_dtype=N.IN_F32, config="vgg"):
+    """The configuration's plan, created through the library at `path`."""
     N._lib = N.bind_library(path)
     plans._plans.clear()            # plans of the previous library stay alive in the caller's list
+    if config == "logmel":
+        from multi_modal_amd import logmel
+        return logmel._plan(device, 400, 160, 80, 16000, False, stream=len(plans._plans) + id(path) % 1000)
+    if config == "har":
+        from multi_modal_amd import har
+        return har._stft_plan(device, 32, 28)
     kw = dict(vggsound._KW)
     plan = kaldi._fbank_plan(device, sample_frequency=kw["sample_frequency"], frame_length=25.0, frame_shift=kw["frame_shift"],
                              num_mel_bins=kw["num_mel_bins"], window_type=kw["window_type"], blackman_coeff=0.42,
@@ -38,7 +48,8 @@ def build_plan(path, device, in_dtype=N.IN_F32):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--config", choices=("vgg", "logmel", "har"), default="vgg")
+    ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--launches", type=int, default=20)
     ap.add_argument("--samples", type=int, default=160000)
@@ -47,17 +58,26 @@ def main():
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(1234)
-    x = (0.1 * torch.randn(args.batch, args.samples, device=dev, generator=g)).clamp_(-1, 1)
+    if args.config == "vgg":
+        rows, n, oshape = args.batch or 4096, args.samples, (384, 128)
+    elif args.config == "logmel":
+        rows, n, oshape = args.batch or 1024, 480000, (80, 3000)
+    else:
+        rows, n, oshape = 6 * (args.batch or 262144), 192, (17, 49)
+    x = torch.empty(rows, n, device=dev)
+    slab = max(1, (1 << 28) // n)
+    for lo in range(0, rows, slab):
+        x[lo:lo + slab] = (0.1 * torch.randn(min(slab, rows - lo), n, device=dev, generator=g)).clamp_(-1, 1)
     names, plist, outs = [], [], []
     for b in args.builds:
         name, path = b.split("=", 1)
         names.append(name)
-        plist.append(build_plan(os.path.abspath(path), 0))
-        outs.append(torch.empty(args.batch, 384, 128, device=dev))
+        plist.append(build_plan(os.path.abspath(path), 0, config=args.config))
+        outs.append(torch.empty((rows,) + oshape, device=dev))
     stream = torch.cuda.current_stream().cuda_stream
 
     def launch(i):
-        plist[i].run_ptr(x.data_ptr(), x.stride(0), args.batch, args.samples, outs[i].data_ptr(), stream)
+        plist[i].run_ptr(x.data_ptr(), x.stride(0), rows, n, outs[i].data_ptr(), stream)
 
     for i in range(len(plist)):
         launch(i)
