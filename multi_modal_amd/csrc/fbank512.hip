@@ -36,7 +36,8 @@ namespace mmfe {
 
 namespace {
 
-constexpr int kFrameLds = 16 * 17 * 8;       // bytes of LDS work space per frame (padded 16x16 complex tile)
+constexpr int kFrameLds = 2176;              // bytes of LDS work space per frame: the 16x16 complex transpose tile with a 16-byte skew per row pair
+                                             // (270 entries of 8 bytes), rounded up so that consecutive tiles start 32 banks apart
 constexpr int kFrameFloats = kFrameLds / 4;  // 544
 constexpr int kPGuard = 8;                   // floats in front of the power spectrum (bin runs may start below 0)
 #ifndef MMFE_FBANK_WAVES
@@ -61,13 +62,20 @@ typedef float mmfe_f32x4 __attribute__((ext_vector_type(4)));
 #define MMFE_OUT_STORE4(a, b, c, d, ptr) (*reinterpret_cast<mmfe_f32x4*>(ptr) = mmfe_f32x4{(a), (b), (c), (d)})
 #endif
 
-#ifndef MMFE_TWIDDLE_REGS
-#define MMFE_TWIDDLE_REGS 2   // where the first-half twiddles W256^(b*c) live.  2: a [c][b] table in LDS (the 16 lanes of a frame read 128
-#endif                        // contiguous bytes, conflict-free), which frees 30 VGPRs and lets a fourth wave per SIMD in: 2.7 % faster than
-                              // 1: 30 VGPRs per lane (3 waves per SIMD);  0: the W256 table in LDS indexed b*c (bank conflicts, slowest)
-#ifndef MMFE_Z_PARK
-#define MMFE_Z_PARK 1         // how the pairs (k, 256-k) of the recombination meet.  0: all of Z is parked in LDS and both members are read
-#endif                        // back; 1: Z[k] stays in the lane's registers (lane b owns k = b + 16 i), only the upper half of Z is parked
+// LDS instruction selection is part of this kernel's design (cycles of the LDS array per wave instruction on gfx950:
+// ds_read_b64 2, ds_read_b128 4, but ds_read2_b64 8 and ds_read2_b32 4; ds_write_b64 6, ds_write2_b64 13), so every
+// LDS and global access below is written with the width it is to be issued with, the kernel opts out of the
+// backend's pairing of DS instructions (target attribute "no-load-store-opt") and this file is compiled with the IR
+// load/store vectoriser off (-mllvm -amdgpu-load-store-vectorizer=0, see the Makefile): left on, it fuses neighbouring
+// 8-byte LDS reads of 8-byte alignment into ds_read2_b64.
+#ifdef __HIP_DEVICE_COMPILE__
+#define MMFE_NO_DS_PAIRING __attribute__((target("no-load-store-opt")))
+#else
+#define MMFE_NO_DS_PAIRING
+#endif
+#ifndef MMFE_MEL_PAIR
+#define MMFE_MEL_PAIR 1       // matrix-pipe mel: every bin run starts on an even bin, so a lane fetches the spectrum operands of two
+#endif                        // steps with one 8-byte LDS read (18 ds_read_b64 = 36 LDS cycles against 36 ds_read_b32 = 72)
 #ifndef MMFE_MEL_ACC_A
 #define MMFE_MEL_ACC_A 1
 #endif
@@ -75,10 +83,22 @@ typedef float mmfe_f32x4 __attribute__((ext_vector_type(4)));
 #define MMFE_MEL_ACC_B 1
 #endif
 constexpr int kWavesPerBlock = MMFE_FBANK_WAVES;
-constexpr int kTwPostEntries = 144;          // -i*W512^k for k = 0..143
+constexpr int kTwPostEntries = 144;          // -i*W512^k for k = 0..143 (the kernel uses the first 128)
 constexpr int kMaxPass = MelPassTable::kMaxPass;
+constexpr int kTw4Entries = 8 * 16, kPost4Entries = 4 * 16, kWin4Entries = 8 * 16;     // 16-byte entries of the LDS tables
+constexpr int kTableBytes = 16 * (kTw4Entries + kPost4Entries + kWin4Entries);         // 5120
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// Explicit-width accesses (see the note on LDS instruction selection above).
+__device__ __forceinline__ float2 ld8(const void* p) {
+    const f32x2 v = *static_cast<const f32x2*>(p);
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ f32x4 ld16(const void* p) { return *static_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st8(void* p, float2 v) { *static_cast<f32x2*>(p) = f32x2{v.x, v.y}; }
 
 struct FbankArgs {
     RowSource src;
@@ -147,11 +167,10 @@ __device__ __forceinline__ void load_frame(float2 (&v)[NA], const float* fp, con
         if (VEC2) {
             const bool ok = whole || idx + 1 < win_len;
 #if MMFE_FBANK_NTLOAD
-            typedef float vf2 __attribute__((ext_vector_type(2)));
-            const vf2 rr = __builtin_nontemporal_load(reinterpret_cast<const vf2*>(ok ? base + 32 * a : safe));
+            const f32x2 rr = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(ok ? base + 32 * a : safe));
             const float2 r = make_float2(rr.x, rr.y);
 #else
-            const float2 r = *reinterpret_cast<const float2*>(ok ? base + 32 * a : safe);
+            const float2 r = ld8(ok ? base + 32 * a : safe);
 #endif
             v[a] = whole ? r : make_float2(ok ? r.x : 0.f, ok ? r.y : 0.f);
         } else {
@@ -211,26 +230,35 @@ __device__ __forceinline__ int frames_of(const FbankArgs& p, unsigned r) {
 
 template <bool PCM, int NA /* ceil(win_len/32) */, bool VEC2, bool EXACT, int NGA, int NGB /* groups of 4 bins per mel set; NGA == 0: VALU mel */,
           bool RAGGED /* per-row lengths (FbankArgs::src.row_len) */>
-__global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_SIMD) fbank512_kernel(const FbankArgs p) {
+__global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_SIMD) MMFE_NO_DS_PAIRING fbank512_kernel(const FbankArgs p) {
     typedef Input<PCM> In;
     typedef typename In::elem Elem;
     constexpr bool kMfmaMel = NGA > 0;
     constexpr int kStepsA = 4 * NGA, kStepsB = 4 * NGB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* s_tw_stage = reinterpret_cast<float2*>(smem);                      // 256
-    float2* s_tw_post = s_tw_stage + 256;                                      // 144
-    float* s_win = reinterpret_cast<float*>(s_tw_post + kTwPostEntries);       // 512
-    int32_t* s_mel_start = reinterpret_cast<int32_t*>(s_win + 512);            // VALU mel only: kMaxPass*16
+    // constant tables, laid out so that each lane fetches two entries with one 16-byte read (the 16 lanes of a frame read 256
+    // contiguous bytes, and the four frame groups read the same addresses):
+    f32x4* s_tw4 = reinterpret_cast<f32x4*>(smem);        // [8][16]: (W256^(b*2j), W256^(b*(2j+1))), the twiddles between the FFT halves
+    f32x4* s_post4 = s_tw4 + kTw4Entries;                 // [4][16]: (-i*W512^(b+32j), -i*W512^(b+32j+16)), the real-FFT recombination
+    f32x4* s_win4 = s_post4 + kPost4Entries;              // [8][16]: window[64j+2b], [64j+2b+1], [64j+32+2b], [64j+32+2b+1]
+    int32_t* s_mel_start = reinterpret_cast<int32_t*>(s_win4 + kWin4Entries);  // VALU mel only: kMaxPass*16
     float* s_mel_w = reinterpret_cast<float*>(s_mel_start + (kMfmaMel ? 0 : kMaxPass * 16));   // VALU mel only
     char* s_work = reinterpret_cast<char*>(s_mel_w + (kMfmaMel ? 0 : p.mel_rows * 16));
 
-#if MMFE_TWIDDLE_REGS == 2
-    for (int i = threadIdx.x; i < 240; i += blockDim.x) s_tw_stage[i] = p.tw_stage[(i & 15) * ((i >> 4) + 1)];      // [c - 1][b] = W256^(b*c)
-#else
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_tw_stage[i] = p.tw_stage[i];
-#endif
-    for (int i = threadIdx.x; i < kTwPostEntries; i += blockDim.x) s_tw_post[i] = p.tw_post[i];
-    for (int i = threadIdx.x; i < 512; i += blockDim.x) s_win[i] = p.window[i];
+    for (int i = threadIdx.x; i < kTw4Entries; i += blockDim.x) {
+        const int j = i >> 4, bb = i & 15;
+        const float2 t0 = p.tw_stage[bb * (2 * j)], t1 = p.tw_stage[bb * (2 * j + 1)];
+        s_tw4[i] = f32x4{t0.x, t0.y, t1.x, t1.y};
+    }
+    for (int i = threadIdx.x; i < kPost4Entries; i += blockDim.x) {
+        const int j = i >> 4, bb = i & 15;
+        const float2 t0 = p.tw_post[bb + 32 * j], t1 = p.tw_post[bb + 32 * j + 16];
+        s_post4[i] = f32x4{t0.x, t0.y, t1.x, t1.y};
+    }
+    for (int i = threadIdx.x; i < kWin4Entries; i += blockDim.x) {
+        const int j = i >> 4, bb = i & 15;
+        s_win4[i] = f32x4{p.window[64 * j + 2 * bb], p.window[64 * j + 2 * bb + 1], p.window[64 * j + 32 + 2 * bb], p.window[64 * j + 32 + 2 * bb + 1]};
+    }
     if (!kMfmaMel) {
         for (int i = threadIdx.x; i < p.n_pass * 16; i += blockDim.x) s_mel_start[i] = p.mel_start[i];
         for (int i = threadIdx.x; i < p.mel_rows * 16; i += blockDim.x) s_mel_w[i] = p.mel_w[i];
@@ -277,11 +305,6 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
     // where masked lanes read: the first win_len samples of row 0, or (ragged batches: row 0 may be shorter than a window) of the buffer
     const Elem* safe = RAGGED ? static_cast<const Elem*>(p.src.base) : row_ptr_as<Elem>(p.src, 0);
     int fv = frames_of<RAGGED>(p, row);                                       // of the quad whose samples are in `nxt`
-#if MMFE_TWIDDLE_REGS == 1
-    float2 twr[15];                             // W256^(b*c), c = 1..15: resident for the life of the kernel
-#pragma unroll
-    for (int c = 1; c < 16; ++c) twr[c - 1] = p.tw_stage[b * c];
-#endif
     float none_flag = p.la.none_flag;
     asm volatile("" : "+v"(none_flag));         // a per-lane value from here on: selects on it stay v_cndmask
     typename In::slice nxt[NA];
@@ -320,6 +343,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
         float2 y[16];
         {
             const float c = p.preemph;
+            f32x4 w4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 // the sample before g[a].x lives in lane b-1 (.y, same a); for lane 0 it is lane 15's
@@ -330,8 +354,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
                 const float prev = dpp_upd<DPP_ROW_SHR1>(edge, g[a].y);
                 const float y0 = g[a].x - c * prev;
                 const float y1 = g[a].y - c * g[a].x;
-                const float2 w = *reinterpret_cast<const float2*>(s_win + 32 * a + 2 * b);
-                y[a] = make_float2(y0 * w.x, y1 * w.y);
+                if ((a & 1) == 0) w4 = ld16(s_win4 + (a >> 1) * 16 + b);
+                y[a] = (a & 1) == 0 ? make_float2(y0 * w4.x, y1 * w4.y) : make_float2(y0 * w4.z, y1 * w4.w);
             }
 #pragma unroll
             for (int a = NA; a < 16; ++a) y[a] = make_float2(0.f, 0.f);
@@ -340,23 +364,31 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
         // ---- 256-point complex FFT, first half: 16-point FFT over a, twiddle, transpose --------
         MMFE_STAMP(1);
         fft16(y);
+        // Transpose tile: row c starts at float2 index 16c + 2(c>>1).  A lane writes 8 bytes per row (16 lanes: 128 contiguous
+        // bytes) and reads its own row back with eight 16-byte reads; the 2-entry skew per row pair spreads the 16 rows that one
+        // 16-byte read touches (lanes {0-3, 12-15} of one frame group with lanes {4-11} of the next) over all 64 banks.
+        {
+            f32x4 tw4 = f32x4{1.f, 0.f, 1.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            float2 val = y[fft16_pos(c)];
-#if MMFE_TWIDDLE_REGS == 1
-            if (c > 0) val = cmul(val, twr[c - 1]);
-#elif MMFE_TWIDDLE_REGS == 2
-            if (c > 0) val = cmul(val, s_tw_stage[(c - 1) * 16 + b]);
-#else
-            if (c > 0) val = cmul(val, s_tw_stage[b * c]);
-#endif
-            fbuf[c * 17 + b] = val;
+            for (int c = 0; c < 16; ++c) {
+                float2 val = y[fft16_pos(c)];
+                if ((c & 1) == 0) tw4 = ld16(s_tw4 + (c >> 1) * 16 + b);
+                if (c > 0) val = cmul(val, (c & 1) == 0 ? make_float2(tw4.x, tw4.y) : make_float2(tw4.z, tw4.w));
+                st8(fbuf + c * 16 + 2 * (c >> 1) + b, val);
+            }
         }
         wave_lds_fence();
         MMFE_STAMP(2);
         float2 u[16];
+        {
+            const float2* trow = fbuf + 16 * b + 2 * (b >> 1);
 #pragma unroll
-        for (int bb = 0; bb < 16; ++bb) u[bb] = fbuf[b * 17 + bb];
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 v = ld16(trow + 2 * j);
+                u[2 * j] = make_float2(v.x, v.y);
+                u[2 * j + 1] = make_float2(v.z, v.w);
+            }
+        }
         wave_lds_fence();
 
         // ---- second half: lane c = b now owns Z[c + 16 d]; park Z in natural order --------------
@@ -366,7 +398,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
         // 16 - b (register 16 - i of lane 0 itself when b = 0), i.e. always one of the upper eight registers of some lane:
         // only those go through LDS.  The one exception, Z[256 - 0] = Z[0], is lane 0's own register 0.
 #pragma unroll
-        for (int d = MMFE_Z_PARK ? 8 : 0; d < 16; ++d) fbuf[b + 16 * d] = u[fft16_pos(d)];
+        for (int d = 8; d < 16; ++d) st8(fbuf + b + 16 * d, u[fft16_pos(d)]);
         // bin 128 pairs with itself: X[128] = 2*conj(Z[128]) (window pre-halved), and Z[128] is lane 0's d = 8
         const float p128 = 4.0f * (u[fft16_pos(8)].x * u[fft16_pos(8)].x + u[fft16_pos(8)].y * u[fft16_pos(8)].y);
         wave_lds_fence();
@@ -389,18 +421,15 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
         }
         MMFE_STAMP(4);
         float pk[8], pq[8];
+        f32x4 post4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int k = b + 16 * i;
-#if MMFE_Z_PARK
             const float2 zk = u[fft16_pos(i)];
-            float2 zp = fbuf[(256 - k) & 255];
+            float2 zp = ld8(fbuf + ((256 - k) & 255));
             if (i == 0) zp = make_float2(b == 0 ? zk.x : zp.x, b == 0 ? zk.y : zp.y);
-#else
-            const float2 zk = fbuf[k];
-            const float2 zp = fbuf[(256 - k) & 255];
-#endif
-            const float2 tw = s_tw_post[k];
+            if ((i & 1) == 0) post4 = ld16(s_post4 + (i >> 1) * 16 + b);
+            const float2 tw = (i & 1) == 0 ? make_float2(post4.x, post4.y) : make_float2(post4.z, post4.w);
             const float2 E = make_float2(zk.x + zp.x, zk.y - zp.y);
             const float2 D = make_float2(zk.x - zp.x, zk.y + zp.y);
             const float2 G = cmul(tw, D);
@@ -429,12 +458,27 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
             for (int i = 0; i < kAccA; ++i) pa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < kAccB; ++i) pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if MMFE_MEL_PAIR
+#pragma unroll
+            for (int s = 0; s < kStepsA; s += 2) {
+                const float2 pv = ld8(pa_A + s);
+                pa[s % kAccA] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[s], pv.x, pa[s % kAccA], 0, 0, 0);
+                pa[(s + 1) % kAccA] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[s + 1], pv.y, pa[(s + 1) % kAccA], 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < kStepsB; s += 2) {
+                const float2 pv = ld8(pa_B + s);
+                pb[s % kAccB] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[kStepsA + s], pv.x, pb[s % kAccB], 0, 0, 0);
+                pb[(s + 1) % kAccB] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[kStepsA + s + 1], pv.y, pb[(s + 1) % kAccB], 0, 0, 0);
+            }
+#else
 #pragma unroll
             for (int s = 0; s < kStepsA; ++s)
                 pa[s % kAccA] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[s], pa_A[s], pa[s % kAccA], 0, 0, 0);
 #pragma unroll
             for (int s = 0; s < kStepsB; ++s)
                 pb[s % kAccB] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[kStepsA + s], pa_B[s], pb[s % kAccB], 0, 0, 0);
+#endif
             f32x4 accA = pa[0], accB = pb[0];
 #pragma unroll
             for (int i = 1; i < kAccA; ++i) accA += pa[i];
@@ -473,9 +517,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
                     unsigned short* orow = static_cast<unsigned short*>(p.out) + oidx;
                     if (p.vec_out) {
                         if (f0 < p.n_mel)
-                            *reinterpret_cast<uint2*>(orow) = make_uint2(pack2_bits(vab[0], vab[1], p.out_dtype), pack2_bits(vab[2], vab[3], p.out_dtype));
+                            *reinterpret_cast<u32x2*>(orow) = u32x2{pack2_bits(vab[0], vab[1], p.out_dtype), pack2_bits(vab[2], vab[3], p.out_dtype)};
                         if (NGB > 0 && 64 + f0 < p.n_mel)
-                            *reinterpret_cast<uint2*>(orow + 64) = make_uint2(pack2_bits(vab[4], vab[5], p.out_dtype), pack2_bits(vab[6], vab[7], p.out_dtype));
+                            *reinterpret_cast<u32x2*>(orow + 64) = u32x2{pack2_bits(vab[4], vab[5], p.out_dtype), pack2_bits(vab[6], vab[7], p.out_dtype)};
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
@@ -577,7 +621,8 @@ static bool build_mel4(Plan& plan, bool align) {
             }
             if (kmax < 0) { kstart[h][blk] = 0; continue; }
             int ks = kmin;
-            if (align) ks = kmin - (((kmin - blk) % 8 + 8) % 8);     // run start = blk (mod 8): conflict-free LDS reads
+            if (MMFE_MEL_PAIR) ks &= ~1;                             // 8-byte operand reads: even run starts
+            if (align && !MMFE_MEL_PAIR) ks = kmin - (((kmin - blk) % 8 + 8) % 8);     // run start = blk (mod 8): conflict-free LDS reads
             if (ks < -kPGuard) ks = kmin;
             kstart[h][blk] = ks;
             steps[h] = std::max(steps[h], kmax - ks + 1);
@@ -617,7 +662,7 @@ static bool build_mel4(Plan& plan, bool align) {
                     const int i = order[oi], blk = 8 * half + i;
                     const int slack = run[i] == 0 ? 7 : std::min(7, budget - run[i]);
                     int chosen = 0;
-                    for (int sh = 0; sh <= slack; ++sh) {
+                    for (int sh = 0; sh <= slack; sh += MMFE_MEL_PAIR ? 2 : 1) {
                         const int cand = kstart[h][blk] - sh;
                         if (cand < -kPGuard) break;
                         if (!used[((cand % 8) + 8) % 8]) { chosen = sh; break; }
@@ -785,7 +830,7 @@ int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
     a.mel4_w = plan.d_mel4_w;
 
     const bool mfma = plan.mel4_nga > 0;
-    const size_t tables = 256 * 8 + kTwPostEntries * 8 + 512 * 4 + (mfma ? 0 : kMaxPass * 16 * 4 + (size_t)a.mel_rows * 64);
+    const size_t tables = kTableBytes + (mfma ? 0 : kMaxPass * 16 * 4 + (size_t)a.mel_rows * 64);
     const size_t lds = tables + (size_t)kWavesPerBlock * 4 * kFrameLds;
     if (lds > 160 * 1024) {
         set_error("fbank512: mel tap table does not fit in LDS (%zu bytes)", lds);

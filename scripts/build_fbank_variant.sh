@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/.."
 NAME=$1; shift
 mkdir -p build/$NAME
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-signed-zeros -fno-slp-vectorize -Wall -Wno-unused-function "$@" \
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-signed-zeros -fno-slp-vectorize -Wall -Wno-unused-function -mllvm -amdgpu-load-store-vectorizer=0 "$@" \
     -Iinclude -Imulti_modal_amd/csrc -Rpass-analysis=kernel-resource-usage -c multi_modal_amd/csrc/fbank512.hip -o build/$NAME/fbank512.o 2> build/$NAME/remarks.txt || { cat build/$NAME/remarks.txt | grep -v remark; exit 1; }
 B=multi_modal_amd/csrc/build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libmmfe_$NAME.so build/$NAME/fbank512.o $B/mmfe_api.o $B/stft32.o $B/dftgen.o $B/rfft400.o $B/frame_stats.o
