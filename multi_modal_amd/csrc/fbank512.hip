@@ -32,6 +32,9 @@
 #include <cstdio>
 #include <cstdlib>
 
+// Contraction is explicit in this file (fmaf where a fused multiply-add is meant), see fft_regs.h.
+#pragma clang fp contract(off)
+
 namespace mmfe {
 
 namespace {
@@ -44,7 +47,9 @@ constexpr int kPGuard = 8;                   // floats in front of the power spe
 #define MMFE_FBANK_WAVES 4
 #endif
 #ifndef MMFE_FBANK_MIN_WAVES_PER_SIMD
-#define MMFE_FBANK_MIN_WAVES_PER_SIMD 4      // 4 blocks of 4 waves per CU: 128 VGPRs per lane, 4 x 40064 B of LDS
+#define MMFE_FBANK_MIN_WAVES_PER_SIMD 3      // 3 blocks of 4 waves per CU, up to 168 VGPRs per lane: room for a prefetch that is requested a whole
+                                             // iteration ahead.  4 (128 VGPRs) runs the FFT phases faster but has to request the prefetch half an
+                                             // iteration later; measured 1.5-2 % slower overall, and with the early prefetch it spills
 #endif
 // output stores: the feature tensor is far larger than the caches, so it can bypass them (1) or not (0)
 #ifndef MMFE_FBANK_NTLOAD
@@ -73,6 +78,9 @@ typedef float mmfe_f32x4 __attribute__((ext_vector_type(4)));
 #else
 #define MMFE_NO_DS_PAIRING
 #endif
+#ifndef MMFE_PREFETCH_EARLY
+#define MMFE_PREFETCH_EARLY 1  // 1: the next quad's samples are requested as soon as this quad's have been windowed (a whole iteration ahead)
+#endif
 #ifndef MMFE_MEL_PAIR
 #define MMFE_MEL_PAIR 1       // matrix-pipe mel: every bin run starts on an even bin, so a lane fetches the spectrum operands of two
 #endif                        // steps with one 8-byte LDS read (18 ds_read_b64 = 36 LDS cycles against 36 ds_read_b32 = 72)
@@ -83,6 +91,11 @@ typedef float mmfe_f32x4 __attribute__((ext_vector_type(4)));
 #define MMFE_MEL_ACC_B 1
 #endif
 constexpr int kWavesPerBlock = MMFE_FBANK_WAVES;
+constexpr int kDefaultChunk = 1;
+#ifndef MMFE_PREFETCH_SPLIT
+#define MMFE_PREFETCH_SPLIT 6
+#endif
+constexpr int kPrefetchSplit = MMFE_PREFETCH_SPLIT;
 constexpr int kTwPostEntries = 144;          // -i*W512^k for k = 0..143 (the kernel uses the first 128)
 constexpr int kMaxPass = MelPassTable::kMaxPass;
 constexpr int kTw4Entries = 8 * 16, kPost4Entries = 4 * 16, kWin4Entries = 8 * 16;     // 16-byte entries of the LDS tables
@@ -112,6 +125,7 @@ struct FbankArgs {
     int win_len;
     int n_mel;
     int vec_out;               // n_mel % 4 == 0 and a 16-byte aligned output tensor: 16-byte stores
+    int chunk;                 // consecutive quads a wave takes per visit (>= 1)
     float preemph;
     float mean_scale;          // 1/win_len when the per-frame mean is removed, else 0
     LogAffine la;
@@ -157,11 +171,11 @@ template <> struct Input<true> {
 // slice that sits in the zero padding read `safe` and select zero.  EXACT promises
 // 32*(NA-1) < win_len <= 32*NA, so only the last slice needs the per-lane test and all other loads
 // are one base register plus an immediate offset.  The VEC2 form needs an even win_len.
-template <int NA, bool VEC2, bool EXACT>
+template <int NA, bool VEC2, bool EXACT, int A0 = 0, int A1 = NA>
 __device__ __forceinline__ void load_frame(float2 (&v)[NA], const float* fp, const float* safe, bool valid, int b, int win_len) {
     const float* base = (valid ? fp : safe) + 2 * b;
 #pragma unroll
-    for (int a = 0; a < NA; ++a) {
+    for (int a = A0; a < A1; ++a) {
         const int idx = 32 * a + 2 * b;
         const bool whole = EXACT && a < NA - 1;        // compile-time: slice entirely inside the window
         if (VEC2) {
@@ -183,11 +197,11 @@ __device__ __forceinline__ void load_frame(float2 (&v)[NA], const float* fp, con
 }
 
 // The same for 16-bit PCM: one 4-byte load per slice (VEC2: needs 4-byte aligned frame starts) or two 2-byte loads.
-template <int NA, bool VEC2, bool EXACT>
+template <int NA, bool VEC2, bool EXACT, int A0 = 0, int A1 = NA>
 __device__ __forceinline__ void load_frame(uint32_t (&v)[NA], const int16_t* fp, const int16_t* safe, bool valid, int b, int win_len) {
     const int16_t* base = (valid ? fp : safe) + 2 * b;
 #pragma unroll
-    for (int a = 0; a < NA; ++a) {
+    for (int a = A0; a < A1; ++a) {
         const int idx = 32 * a + 2 * b;
         const bool whole = EXACT && a < NA - 1;
         if (VEC2) {
@@ -202,6 +216,15 @@ __device__ __forceinline__ void load_frame(uint32_t (&v)[NA], const int16_t* fp,
         }
     }
 }
+
+// How the rows of a launch end (template parameter MODE of the kernel):
+//   kRowsWhole   every row has the same number of frames, a multiple of 4, and the output is float32 with whole 16-byte
+//                filter blocks: every lane of every quad stores, unconditionally.  This matters beyond the saved compares:
+//                loads and stores share one in-order counter (vmcnt), so a wave can wait for "my prefetched samples, but
+//                not the stores I issued after them" only if the number of those stores is the same on every path.
+//   kRowsAny     every row has the same number of frames; stores are predicated
+//   kRowsRagged  per-row lengths (FbankArgs::src.row_len)
+constexpr int kRowsWhole = 0, kRowsAny = 1, kRowsRagged = 2;
 
 // Frames computed for row r (wave-uniform): the launch-wide count, or in a ragged batch what the row's own length gives.
 template <bool RAGGED>
@@ -229,10 +252,11 @@ __device__ __forceinline__ int frames_of(const FbankArgs& p, unsigned r) {
 #endif
 
 template <bool PCM, int NA /* ceil(win_len/32) */, bool VEC2, bool EXACT, int NGA, int NGB /* groups of 4 bins per mel set; NGA == 0: VALU mel */,
-          bool RAGGED /* per-row lengths (FbankArgs::src.row_len) */>
+          int MODE /* kRowsWhole, kRowsAny or kRowsRagged */>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_SIMD) MMFE_NO_DS_PAIRING fbank512_kernel(const FbankArgs p) {
     typedef Input<PCM> In;
     typedef typename In::elem Elem;
+    constexpr bool RAGGED = MODE == kRowsRagged, WHOLE = MODE == kRowsWhole;
     constexpr bool kMfmaMel = NGA > 0;
     constexpr int kStepsA = 4 * NGA, kStepsB = 4 * NGB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -289,16 +313,22 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
         pa_B = slot + p.mel4_kstart[64 + lane];
     }
 
-    // work distribution: quad = 4 consecutive frames of one row; a block takes kWavesPerBlock consecutive
-    // quads per round so that its waves stream one contiguous region
+    // work distribution: quad = 4 consecutive frames of one row.  The quads are cut into runs of p.chunk consecutive quads
+    // and the runs dealt round-robin to the grid's waves (the waves of a block take neighbouring runs), so that a wave
+    // streams p.chunk * 4 frames of contiguous input and output per visit and a block one contiguous region.
     const unsigned qpr = (unsigned)(p.frames_valid + 3) >> 2;      // quads per row
-    const unsigned qstride = gridDim.x * kWavesPerBlock;
-    const unsigned d_row = qstride / qpr, d_q = qstride - d_row * qpr;
-    const unsigned quad0 = blockIdx.x * kWavesPerBlock + wave;
+    const unsigned chunk = (unsigned)p.chunk;
+    const unsigned jump = (gridDim.x * kWavesPerBlock - 1) * chunk + 1;        // from the last quad of a run to the first of the wave's next
+    const unsigned d_row = jump / qpr, d_q = jump - d_row * qpr;
+    const unsigned quad0 = (blockIdx.x * kWavesPerBlock + wave) * chunk;
     unsigned row = quad0 / qpr, q = quad0 - row * qpr;              // wave-uniform
+    unsigned in_run = 0;
     auto advance = [&](unsigned& r, unsigned& qq) {
-        r += d_row;
-        qq += d_q;
+        in_run += 1;
+        const bool last = in_run == chunk;
+        if (last) in_run = 0;
+        r += last ? d_row : 0u;
+        qq += last ? d_q : 1u;
         if (qq >= qpr) { qq -= qpr; r += 1; }
     };
 
@@ -314,6 +344,20 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
         const Elem* fp = row_ptr_as<Elem>(p.src, valid ? row : 0) + (int64_t)t * p.hop;
         load_frame<NA, VEC2, EXACT>(nxt, fp, safe, valid, b, p.win_len);
     }
+    // The lane's share of the frame sum (DC removal) is taken at the END of an iteration, after the output stores have been
+    // issued: it is the first use of the prefetched samples, so the wait for them stands behind the stores in program order
+    // and can leave exactly those outstanding.  At the top of the loop the same wait would also have to cover the path
+    // from the prologue, i.e. drain every store of the previous iteration before any arithmetic starts.
+    auto lane_sum = [&]() {
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const float2 v = In::unpack(nxt[a]);
+            s += v.x + v.y;
+        }
+        return s;
+    };
+    float dc_part = lane_sum();
 
 #ifdef MMFE_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
@@ -330,10 +374,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
 
         // ---- per-frame DC removal (kaldi remove_dc_offset) ------------------------------------
         {
-            float s = 0.f;
-#pragma unroll
-            for (int a = 0; a < NA; ++a) s += g[a].x + g[a].y;
-            const float mean = row16_sum(s) * p.mean_scale;       // mean_scale = 0 switches the removal off
+            const float mean = row16_sum(dc_part) * p.mean_scale;       // mean_scale = 0 switches the removal off
 #pragma unroll
             for (int a = 0; a < NA; ++a) { g[a].x -= mean; g[a].y -= mean; }
         }
@@ -352,8 +393,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
                 if (a == 0) edge = g[0].x;
                 else edge = dpp_mov<DPP_ROW_ROR1>(g[a - 1 < 0 ? 0 : a - 1].y);
                 const float prev = dpp_upd<DPP_ROW_SHR1>(edge, g[a].y);
-                const float y0 = g[a].x - c * prev;
-                const float y1 = g[a].y - c * g[a].x;
+                const float y0 = fmaf(-c, prev, g[a].x);
+                const float y1 = fmaf(-c, g[a].x, g[a].y);
                 if ((a & 1) == 0) w4 = ld16(s_win4 + (a >> 1) * 16 + b);
                 y[a] = (a & 1) == 0 ? make_float2(y0 * w4.x, y1 * w4.y) : make_float2(y0 * w4.z, y1 * w4.w);
             }
@@ -361,6 +402,24 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
             for (int a = NA; a < 16; ++a) y[a] = make_float2(0.f, 0.f);
         }
 
+        // prefetch of the wave's next quad: requested here (MMFE_PREFETCH_EARLY 1: a whole iteration ahead, 26 registers live
+        // through both FFT halves), after the second FFT half (0: half an iteration ahead, where register pressure is
+        // lowest), or the first kPrefetchSplit slices here and the rest there (2)
+        const Elem* nfp = nullptr;
+        bool nvalid = false;
+        if (MMFE_PREFETCH_EARLY) {
+            advance(row, q);
+            const int nt = (int)q * 4 + fl;
+            fv = frames_of<RAGGED>(p, row);
+            nvalid = row < (unsigned)p.n_rows && nt < fv;
+            nfp = row_ptr_as<Elem>(p.src, row < (unsigned)p.n_rows ? row : 0) + (int64_t)nt * p.hop;
+#ifdef MMFE_ABL_NOLOAD
+#pragma unroll
+            for (int a = 0; a < NA; ++a) nxt[a] = In::perturb(nxt[a], nt);
+#else
+            load_frame<NA, VEC2, EXACT, 0, MMFE_PREFETCH_EARLY == 2 ? kPrefetchSplit : NA>(nxt, nfp, safe, nvalid, b, p.win_len);
+#endif
+        }
         // ---- 256-point complex FFT, first half: 16-point FFT over a, twiddle, transpose --------
         MMFE_STAMP(1);
         fft16(y);
@@ -400,25 +459,27 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
 #pragma unroll
         for (int d = 8; d < 16; ++d) st8(fbuf + b + 16 * d, u[fft16_pos(d)]);
         // bin 128 pairs with itself: X[128] = 2*conj(Z[128]) (window pre-halved), and Z[128] is lane 0's d = 8
-        const float p128 = 4.0f * (u[fft16_pos(8)].x * u[fft16_pos(8)].x + u[fft16_pos(8)].y * u[fft16_pos(8)].y);
+        const float p128 = 4.0f * fmaf(u[fft16_pos(8)].x, u[fft16_pos(8)].x, u[fft16_pos(8)].y * u[fft16_pos(8)].y);
         wave_lds_fence();
 
         // ---- real-FFT recombination on pairs (k, 256-k), power spectrum ------------------------
         // prefetch the next quad of this wave here, where register pressure is lowest (both FFT halves are done
         // and only Z in LDS is live); the loads stay in flight under the rest of this iteration
-        advance(row, q);
-        {
+        if (!MMFE_PREFETCH_EARLY) {
+            advance(row, q);
             const int nt = (int)q * 4 + fl;
             fv = frames_of<RAGGED>(p, row);
-            const bool nvalid = row < (unsigned)p.n_rows && nt < fv;
-            const Elem* nfp = row_ptr_as<Elem>(p.src, row < (unsigned)p.n_rows ? row : 0) + (int64_t)nt * p.hop;
+            nvalid = row < (unsigned)p.n_rows && nt < fv;
+            nfp = row_ptr_as<Elem>(p.src, row < (unsigned)p.n_rows ? row : 0) + (int64_t)nt * p.hop;
 #ifdef MMFE_ABL_NOLOAD
 #pragma unroll
             for (int a = 0; a < NA; ++a) nxt[a] = In::perturb(nxt[a], nt);
-#else
-            load_frame<NA, VEC2, EXACT>(nxt, nfp, safe, nvalid, b, p.win_len);
 #endif
         }
+#ifndef MMFE_ABL_NOLOAD
+        if (MMFE_PREFETCH_EARLY != 1)
+            load_frame<NA, VEC2, EXACT, MMFE_PREFETCH_EARLY == 2 ? kPrefetchSplit : 0, NA>(nxt, nfp, safe, nvalid, b, p.win_len);
+#endif
         MMFE_STAMP(4);
         float pk[8], pq[8];
         f32x4 post4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -434,8 +495,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
             const float2 D = make_float2(zk.x - zp.x, zk.y + zp.y);
             const float2 G = cmul(tw, D);
             const float2 xa = cadd(E, G), xb = csub(E, G);
-            pk[i] = xa.x * xa.x + xa.y * xa.y;          // |X[k]|^2
-            pq[i] = xb.x * xb.x + xb.y * xb.y;          // |X[256-k]|^2
+            pk[i] = fmaf(xa.x, xa.x, xa.y * xa.y);      // |X[k]|^2
+            pq[i] = fmaf(xb.x, xb.x, xb.y * xb.y);      // |X[256-k]|^2
         }
         wave_lds_fence();
 #pragma unroll
@@ -496,6 +557,16 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
             const int n_ok = cur_fv - t0;                 // wave-uniform; <= 0 for a quad past the end of a short row
             const int q4 = lane & 3, f0 = lane & ~3;      // frame slot, first filter of the lane's block
             const int64_t oidx = ((int64_t)cur_row * p.out_rows + t0 + q4) * p.n_mel + f0;
+            if constexpr (WHOLE) {
+                float* orow = static_cast<float*>(p.out) + oidx;
+#ifdef MMFE_ABL_NOSTORE
+                if (vab[0] == 123.456f && vab[5] == 654.321f)
+#endif
+                {
+                    MMFE_OUT_STORE4(vab[0], vab[1], vab[2], vab[3], orow);
+                    if (NGB > 0) MMFE_OUT_STORE4(vab[4], vab[5], vab[6], vab[7], orow + 64);
+                }
+            } else
 #ifdef MMFE_ABL_NOSTORE
             if (q4 < n_ok && vab[0] == 123.456f && vab[5] == 654.321f) {
 #else
@@ -552,6 +623,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
         st_acc[7] += 1;
 #endif
         wave_lds_fence();
+        __builtin_amdgcn_sched_barrier(0);      // the sum below stays behind the stores
+        dc_part = lane_sum();
     }
 #ifdef MMFE_STAMPS
     if (lane == 0)
@@ -560,10 +633,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
 }
 
 // `want` blocks cover the batch once; the grid is persistent, at most `per_cu` blocks on each CU of the current device.
-template <bool PCM, int NA, bool VEC2, bool EXACT, int NGA, int NGB, bool RAGGED>
+template <bool PCM, int NA, bool VEC2, bool EXACT, int NGA, int NGB, int MODE>
 int launch_variant(const FbankArgs& args, int64_t want, int per_cu, size_t lds, hipStream_t stream) {
     int resident = 0, cus = 0;      // raises the variant's dynamic-LDS limit on this device (once) and returns the cached CU count
-    const int prc = kernel_prepare(reinterpret_cast<const void*>(&fbank512_kernel<PCM, NA, VEC2, EXACT, NGA, NGB, RAGGED>), 64 * kWavesPerBlock, lds,
+    const int prc = kernel_prepare(reinterpret_cast<const void*>(&fbank512_kernel<PCM, NA, VEC2, EXACT, NGA, NGB, MODE>), 64 * kWavesPerBlock, lds,
                                    &resident, &cus);
     if (prc) return prc;
     const int grid = (int)std::min<int64_t>(want, (int64_t)cus * per_cu);
@@ -572,7 +645,7 @@ int launch_variant(const FbankArgs& args, int64_t want, int per_cu, size_t lds, 
     const size_t n_st = (size_t)grid * kWavesPerBlock * 8;
     MMFE_HIP_CHECK(hipMalloc((void**)&targs.stamps, n_st * 8));
     MMFE_HIP_CHECK(hipMemset(targs.stamps, 0, n_st * 8));
-    hipLaunchKernelGGL((fbank512_kernel<PCM, NA, VEC2, EXACT, NGA, NGB, RAGGED>), dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, targs);
+    hipLaunchKernelGGL((fbank512_kernel<PCM, NA, VEC2, EXACT, NGA, NGB, MODE>), dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, targs);
     MMFE_HIP_CHECK(hipDeviceSynchronize());
     std::vector<unsigned long long> h(n_st);
     MMFE_HIP_CHECK(hipMemcpy(h.data(), targs.stamps, n_st * 8, hipMemcpyDeviceToHost));
@@ -588,7 +661,7 @@ int launch_variant(const FbankArgs& args, int64_t want, int per_cu, size_t lds, 
     }
     return MMFE_OK;
 #else
-    hipLaunchKernelGGL((fbank512_kernel<PCM, NA, VEC2, EXACT, NGA, NGB, RAGGED>), dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, args);
+    hipLaunchKernelGGL((fbank512_kernel<PCM, NA, VEC2, EXACT, NGA, NGB, MODE>), dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, args);
     MMFE_HIP_CHECK(hipGetLastError());
     return MMFE_OK;
 #endif
@@ -742,6 +815,7 @@ int fbank512_prepare(Plan& plan) {
     // at the price of longer runs; measured slower than the shorter unaligned runs, so it is off by default)
     // tuning knobs are read here, once per plan, never on the launch path
     if (const char* e = std::getenv("MMFE_FBANK_BLOCKS_PER_CU")) plan.tune_blocks_per_cu = std::atoi(e);     // fewer resident blocks per CU
+    if (const char* e = std::getenv("MMFE_FBANK_CHUNK")) plan.tune_chunk = std::atoi(e);                     // quads per wave visit
     const char* form = std::getenv("MMFE_MEL_FORM");
     const char* al = std::getenv("MMFE_MEL_ALIGN");
     const bool want_mfma = !(form != nullptr && std::string(form) == "valu");
@@ -837,10 +911,11 @@ int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
         return MMFE_EINVAL;
     }
     const int blocks_per_cu = std::max<int>(1, (int)((160 * 1024) / lds));
-    const int64_t want = (quads + kWavesPerBlock - 1) / kWavesPerBlock;
     const int by_waves = std::max(1, (4 * MMFE_FBANK_MIN_WAVES_PER_SIMD) / kWavesPerBlock);
     int per_cu = std::min(blocks_per_cu, by_waves);
     if (plan.tune_blocks_per_cu >= 1 && plan.tune_blocks_per_cu < per_cu) per_cu = plan.tune_blocks_per_cu;
+    a.chunk = std::max(1, std::min(plan.tune_chunk > 0 ? plan.tune_chunk : kDefaultChunk, 1 << 16));
+    const int64_t want = (quads + (int64_t)kWavesPerBlock * a.chunk - 1) / ((int64_t)kWavesPerBlock * a.chunk);
 
     // one load per 2-sample slice needs every frame start aligned to the slice (8 bytes of floats, 4 of PCM)
     const bool pcm = s.in_dtype == MMFE_IN_S16;
@@ -853,20 +928,24 @@ int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
 #define MMFE_FBANK_DISPATCH(NGA_, NGB_)                                                                                  \
     if (nga == NGA_ && ngb == NGB_) {                                                                                    \
         if (ragged) {      /* ragged batches: the forms without a compile-time window length */                          \
-            if (pcm) return vec2 ? launch_variant<true, 16, true, false, NGA_, NGB_, true>(a, want, per_cu, lds, stream)  \
-                                 : launch_variant<true, 16, false, false, NGA_, NGB_, true>(a, want, per_cu, lds, stream); \
-            if (na == 13 && vec2) return launch_variant<false, 13, true, true, NGA_, NGB_, true>(a, want, per_cu, lds, stream); \
-            return vec2 ? launch_variant<false, 16, true, false, NGA_, NGB_, true>(a, want, per_cu, lds, stream)         \
-                        : launch_variant<false, 16, false, false, NGA_, NGB_, true>(a, want, per_cu, lds, stream);       \
+            if (pcm) return vec2 ? launch_variant<true, 16, true, false, NGA_, NGB_, kRowsRagged>(a, want, per_cu, lds, stream)  \
+                                 : launch_variant<true, 16, false, false, NGA_, NGB_, kRowsRagged>(a, want, per_cu, lds, stream); \
+            if (na == 13 && vec2) return launch_variant<false, 13, true, true, NGA_, NGB_, kRowsRagged>(a, want, per_cu, lds, stream); \
+            return vec2 ? launch_variant<false, 16, true, false, NGA_, NGB_, kRowsRagged>(a, want, per_cu, lds, stream)         \
+                        : launch_variant<false, 16, false, false, NGA_, NGB_, kRowsRagged>(a, want, per_cu, lds, stream);       \
         }                                                                                                                \
+        const bool whole = NGA_ > 0 && frames_valid % 4 == 0 && a.vec_out && s.out_dtype == MMFE_OUT_F32 &&              \
+                           s.n_mel == (NGB_ > 0 ? 128 : 64);                                                             \
         if (pcm) {                                                                                                       \
-            if (na == 13 && vec2) return launch_variant<true, 13, true, true, NGA_, NGB_, false>(a, want, per_cu, lds, stream); \
-            return vec2 ? launch_variant<true, 16, true, false, NGA_, NGB_, false>(a, want, per_cu, lds, stream)         \
-                        : launch_variant<true, 16, false, false, NGA_, NGB_, false>(a, want, per_cu, lds, stream);       \
+            if (na == 13 && vec2) return whole ? launch_variant<true, 13, true, true, NGA_, NGB_, kRowsWhole>(a, want, per_cu, lds, stream) \
+                                               : launch_variant<true, 13, true, true, NGA_, NGB_, kRowsAny>(a, want, per_cu, lds, stream); \
+            return vec2 ? launch_variant<true, 16, true, false, NGA_, NGB_, kRowsAny>(a, want, per_cu, lds, stream)      \
+                        : launch_variant<true, 16, false, false, NGA_, NGB_, kRowsAny>(a, want, per_cu, lds, stream);    \
         }                                                                                                                \
-        if (na == 13 && vec2) return launch_variant<false, 13, true, true, NGA_, NGB_, false>(a, want, per_cu, lds, stream); \
-        return vec2 ? launch_variant<false, 16, true, false, NGA_, NGB_, false>(a, want, per_cu, lds, stream)            \
-                    : launch_variant<false, 16, false, false, NGA_, NGB_, false>(a, want, per_cu, lds, stream);          \
+        if (na == 13 && vec2) return whole ? launch_variant<false, 13, true, true, NGA_, NGB_, kRowsWhole>(a, want, per_cu, lds, stream) \
+                                           : launch_variant<false, 13, true, true, NGA_, NGB_, kRowsAny>(a, want, per_cu, lds, stream); \
+        return vec2 ? launch_variant<false, 16, true, false, NGA_, NGB_, kRowsAny>(a, want, per_cu, lds, stream)         \
+                    : launch_variant<false, 16, false, false, NGA_, NGB_, kRowsAny>(a, want, per_cu, lds, stream);       \
     }
     MMFE_FBANK_DISPATCH(2, 7)
     MMFE_FBANK_DISPATCH(3, 8)

@@ -4,10 +4,15 @@
 
 namespace mmfe {
 
+// The fused multiply-adds of the helpers below are written out (fmaf) with the compiler's own contraction off inside
+// them: which products get fused decides the low bits of a spectrum, and left to the optimiser that choice moves
+// with instruction scheduling (two builds of one kernel then differ in the sixth digit of a log-mel value).
+
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+#pragma clang fp contract(off)
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
 }
 
 // 4-point forward DFT in place: (a0,a1,a2,a3) -> (X0,X1,X2,X3), W4 = -i.
@@ -22,16 +27,17 @@ __device__ __forceinline__ void dft4(float2& a0, float2& a1, float2& a2, float2&
 // x *= W16^M  (W16 = exp(-2*pi*i/16)), M a compile-time constant in [0, 9].
 template <int M>
 __device__ __forceinline__ float2 mul_w16(float2 v) {
+#pragma clang fp contract(off)
     constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
     if constexpr (M == 0) return v;
-    else if constexpr (M == 1) return make_float2(v.x * C1 + v.y * S1, v.y * C1 - v.x * S1);
+    else if constexpr (M == 1) return make_float2(fmaf(v.x, C1, v.y * S1), fmaf(v.y, C1, -(v.x * S1)));
     else if constexpr (M == 2) return make_float2((v.x + v.y) * H, (v.y - v.x) * H);
-    else if constexpr (M == 3) return make_float2(v.x * S1 + v.y * C1, v.y * S1 - v.x * C1);
+    else if constexpr (M == 3) return make_float2(fmaf(v.x, S1, v.y * C1), fmaf(v.y, S1, -(v.x * C1)));
     else if constexpr (M == 4) return make_float2(v.y, -v.x);
     else if constexpr (M == 6) return make_float2((v.y - v.x) * H, -(v.x + v.y) * H);
     else {
         static_assert(M == 9, "unsupported W16 power");
-        return make_float2(-v.x * C1 - v.y * S1, v.x * S1 - v.y * C1);   // W16^9 = (-C1, +S1)
+        return make_float2(-fmaf(v.x, C1, v.y * S1), fmaf(v.x, S1, -(v.y * C1)));   // W16^9 = (-C1, +S1)
     }
 }
 
@@ -39,23 +45,55 @@ __device__ __forceinline__ float2 mul_w16(float2 v) {
 // x[fft16_pos(k)] (digit-reversed positions), so callers index with fft16_pos() at compile time.
 __host__ __device__ constexpr int fft16_pos(int k) { return 4 * (k & 3) + (k >> 2); }
 
+// 4-point DFT whose inputs 1 and 3 arrive as H*p1 and H*p3 (H = sqrt(1/2), the W16^2 / W16^6 twiddles): the H rides
+// on the fused multiply-adds of the last butterfly level.
+__device__ __forceinline__ void dft4_h13(float2& a0, float2 p1, float2& a2, float2 p3, float2& o1, float2& o3) {
+#pragma clang fp contract(off)
+    constexpr float H = 0.70710678118654752f;
+    const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), s = cadd(p1, p3), d = csub(p1, p3);
+    a0 = make_float2(fmaf(H, s.x, t0.x), fmaf(H, s.y, t0.y));
+    a2 = make_float2(fmaf(-H, s.x, t0.x), fmaf(-H, s.y, t0.y));
+    o1 = make_float2(fmaf(H, d.y, t1.x), fmaf(-H, d.x, t1.y));
+    o3 = make_float2(fmaf(-H, d.y, t1.x), fmaf(H, d.x, t1.y));
+}
+
+// 4-point DFT whose input 2 arrives as H*p2.
+__device__ __forceinline__ void dft4_h2(float2& a0, float2& a1, float2& a2, float2 p2, float2& a3) {
+#pragma clang fp contract(off)
+    constexpr float H = 0.70710678118654752f;
+    const float2 t0 = make_float2(fmaf(H, p2.x, a0.x), fmaf(H, p2.y, a0.y)), t1 = make_float2(fmaf(-H, p2.x, a0.x), fmaf(-H, p2.y, a0.y));
+    const float2 t2 = cadd(a1, a3), t3 = csub(a1, a3);
+    a0 = cadd(t0, t2);
+    a2 = csub(t0, t2);
+    a1 = make_float2(t1.x + t3.y, t1.y - t3.x);
+    a3 = make_float2(t1.x - t3.y, t1.y + t3.x);
+}
+
 __device__ __forceinline__ void fft16(float2 (&x)[16]) {
     // radix-4 over n1 for each n2: x[4*n1 + n2] -> A[n2][k1] stored at x[4*k1 + n2]
 #pragma unroll
     for (int n2 = 0; n2 < 4; ++n2) dft4(x[n2], x[4 + n2], x[8 + n2], x[12 + n2]);
-    // twiddles W16^(n2*k1)
-    x[4 * 1 + 1] = mul_w16<1>(x[4 * 1 + 1]);
-    x[4 * 1 + 2] = mul_w16<2>(x[4 * 1 + 2]);
-    x[4 * 1 + 3] = mul_w16<3>(x[4 * 1 + 3]);
-    x[4 * 2 + 1] = mul_w16<2>(x[4 * 2 + 1]);
-    x[4 * 2 + 2] = mul_w16<4>(x[4 * 2 + 2]);
-    x[4 * 2 + 3] = mul_w16<6>(x[4 * 2 + 3]);
-    x[4 * 3 + 1] = mul_w16<3>(x[4 * 3 + 1]);
-    x[4 * 3 + 2] = mul_w16<6>(x[4 * 3 + 2]);
-    x[4 * 3 + 3] = mul_w16<9>(x[4 * 3 + 3]);
-    // radix-4 over n2 for each k1: x[4*k1 + k2] = X[k1 + 4*k2]
-#pragma unroll
-    for (int k1 = 0; k1 < 4; ++k1) dft4(x[4 * k1], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);
+    // twiddles W16^(n2*k1), then radix-4 over n2 for each k1: x[4*k1 + k2] = X[k1 + 4*k2].  W16^2 = H*(1 - i) and
+    // W16^6 = -H*(1 + i): those products are left as (sum, difference) pairs and their H is applied inside the butterfly.
+    dft4(x[0], x[1], x[2], x[3]);
+    {   // k1 = 1: twiddles 1, W^1, W^2, W^3
+        x[5] = mul_w16<1>(x[5]);
+        x[7] = mul_w16<3>(x[7]);
+        const float2 p2 = make_float2(x[6].x + x[6].y, x[6].y - x[6].x);
+        dft4_h2(x[4], x[5], x[6], p2, x[7]);
+    }
+    {   // k1 = 2: twiddles 1, W^2, W^4, W^6
+        const float2 p1 = make_float2(x[9].x + x[9].y, x[9].y - x[9].x);
+        const float2 p3 = make_float2(x[11].y - x[11].x, -(x[11].x + x[11].y));
+        x[10] = mul_w16<4>(x[10]);
+        dft4_h13(x[8], p1, x[10], p3, x[9], x[11]);
+    }
+    {   // k1 = 3: twiddles 1, W^3, W^6, W^9
+        x[13] = mul_w16<3>(x[13]);
+        x[15] = mul_w16<9>(x[15]);
+        const float2 p2 = make_float2(x[14].y - x[14].x, -(x[14].x + x[14].y));
+        dft4_h2(x[12], x[13], x[14], p2, x[15]);
+    }
 }
 
 // ---- DPP helpers (16-lane rows) ----------------------------------------------------------------

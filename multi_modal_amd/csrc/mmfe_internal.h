@@ -140,6 +140,7 @@ struct Plan {
     float* d_rowmax = nullptr;        // scratch for clamp_below_max: per-row maxima [0, capacity) and minima [capacity, 2*capacity)
     int64_t rowmax_capacity = 0;
     int tune_blocks_per_cu = 0;       // > 0: upper limit on resident blocks per CU (tuning; read from the environment at plan creation)
+    int tune_chunk = 0;               // > 0: consecutive frame quads a wave takes per visit (tuning, as above)
     int impl = 0;                     // which kernel family serves this plan
 };
 

@@ -2,7 +2,7 @@
 """A/B timing of several builds of libmmfe.so on one benchmark configuration, in ONE process with
 interleaved rounds (separate processes add variance that looks like a kernel property).
 
-    python scripts/ab_fbank.py [--config vgg|logmel|har] [--batch N] [--rounds 6] [--launches 20] name=path.so [name=path.so ...]
+    python scripts/ab_fbank.py [--config vgg|logmel|har] [--batch N] [--rounds 6] [--launches 20] name=path.so[@VAR=VALUE,...] [name=path.so ...]
 
   vgg     VGGSound log-mel, 4096 clips of 160 000 samples (kernel fbank512)
   logmel  long-utterance log-mel, 1024 utterances of 480 000 samples (kernel rfft400 + clamp pass)
@@ -71,8 +71,19 @@ def main():
     names, plist, outs = [], [], []
     for b in args.builds:
         name, path = b.split("=", 1)
+        path, _, envs = path.partition("@")            # name=path@VAR=VALUE,VAR=VALUE: tuning variables read at plan creation
+        saved = {}
+        for kv in filter(None, envs.split(",")):
+            k, v = kv.split("=", 1)
+            saved[k] = os.environ.get(k)
+            os.environ[k] = v
         names.append(name)
         plist.append(build_plan(os.path.abspath(path), 0, config=args.config))
+        for k, v in saved.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
         outs.append(torch.empty((rows,) + oshape, device=dev))
     stream = torch.cuda.current_stream().cuda_stream
 
