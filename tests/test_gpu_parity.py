@@ -933,3 +933,75 @@ def test_stft_mag_other_segment_lengths(mm, O, nperseg, noverlap, t):
     live = np.abs(scipy.signal.stft(x, fs=100, nperseg=nperseg, noverlap=noverlap)[-1])
     assert got.shape == ref.shape == live.shape
     assert np.abs(got - ref).max() <= 1e-6 and np.abs(got - live).max() <= 1e-6
+
+
+def test_log_stage_against_libm(mm):
+    """The log stage alone: the same plan once without the log (the kernel's own mel energies E) and once with it; every cell
+    must equal the libm value of ln(max(E, eps)) to 4e-6 absolute while E sweeps more than 2^-23 ... 2^10 (the hardware
+    base-2 logarithm plus one fused multiply-add; floored cells carry the host-libm value exactly)."""
+    base = synth("noise0.1", 16000, 77)
+    amps = 2.0 ** np.arange(-14, 3.5, 0.5)                     # energies scale with the square: 2^-28 ... 2^6 times the base level
+    x = torch.from_numpy(np.stack([np.clip(a * base * 4.0, -8.0, 8.0) for a in amps]).astype(np.float32)).cuda()
+    kw = dict(sample_frequency=16000.0, window_type="hanning", num_mel_bins=128, frame_shift=25.0)
+    lin = mm.kaldi.fbank_batch(x, use_log_fbank=False, **kw).cpu().numpy().astype(np.float64)
+    got = mm.kaldi.fbank_batch(x, use_log_fbank=True, **kw).cpu().numpy().astype(np.float64)
+    eps = float(np.finfo(np.float32).eps)
+    live = lin[:, :, [m for m in range(128) if m != 3]]        # filter 3 of this bank is empty
+    assert live.min() < 2.0 ** -23 and live.max() > 2.0 ** 10, (live.min(), live.max())
+    want = np.log(np.maximum(lin, eps))
+    d = np.abs(got - want)
+    print("log stage: energies", live.min(), "...", live.max(), "max |d|", d.max())
+    assert d.max() <= 4e-6
+    floored = lin <= eps
+    assert floored.any() and np.all(got[floored] == np.float64(np.float32(np.log(np.float32(eps)))))
+
+
+def test_mel_weights_are_the_kaldi_triangles(mm):
+    """The mel weights the kernels are fed, against an implementation that shares no code with them: the float64 kaldi bank of
+    transformers.audio_utils (when importable) and literal cells of that bank."""
+    from multi_modal_amd import melbank
+    bank = torch.nn.functional.pad(melbank.kaldi_mel_banks(128, 512, 16000.0, 20.0, 0.0), (0, 1)).numpy()
+    cells = {(0, 1): 0.8026399861583207, (127, 250): 0.8720851867439546, (127, 255): 0.1862875061163922, (0, 2): 0.0, (100, 150): 0.0}
+    for (m, k), v in cells.items():
+        assert abs(float(bank[m, k]) - v) <= 2e-5
+    try:
+        from transformers.audio_utils import mel_filter_bank
+    except Exception:
+        pytest.skip("transformers not importable")
+    hf = mel_filter_bank(num_frequency_bins=257, num_mel_filters=128, min_frequency=20.0, max_frequency=8000.0, sampling_rate=16000,
+                         norm=None, mel_scale="kaldi", triangularize_in_mel_space=True)
+    assert np.abs(hf.T - bank).max() <= 2e-5
+    # and through the kernel: linear mel energies of white noise equal (float64 power spectrum of the oracle's windowed frames) x bank
+    x = torch.from_numpy(synth("noise0.1", 4000, 5))[None]
+    lin = mm.kaldi.fbank_batch(x.cuda(), use_log_fbank=False, sample_frequency=16000.0, window_type="hanning", num_mel_bins=128,
+                               frame_shift=25.0).cpu().numpy()[0].astype(np.float64)
+    fr = x[0].double().unfold(0, 400, 400)
+    fr = fr - fr.mean(1, keepdim=True)
+    fr = fr - 0.97 * torch.cat([fr[:, :1], fr[:, :-1]], 1)
+    fr = fr * torch.hann_window(400, periodic=False, dtype=torch.float64)
+    pw = torch.fft.rfft(torch.nn.functional.pad(fr, (0, 112)), dim=1).abs().pow(2).numpy()
+    want = pw @ hf
+    live = want > 1e-3
+    assert np.abs(lin[live] / want[live] - 1.0).max() <= 2e-4
+
+
+def test_epic_golden_fixture(mm, golden_dir):
+    """Stored cells of the EPIC log-spectrogram fixture (rows of the CPU restatement and of the float64 numpy evaluation)."""
+    g = np.load(f"{golden_dir}/epic_logspec.npz")
+    rows = g["rows"]
+    for n in (30672, 30696):
+        for kind in ("noise0.1", "quiet", "silence", "sine+noise"):
+            y = mm.log_specgram(synth(kind, n, 4242 + n))
+            assert np.abs(y[rows] - g[f"{kind}_{n}_rows"]).max() <= 1e-4
+            assert np.abs(y[rows] - g[f"{kind}_{n}_np64_rows"]).max() <= 1e-4
+            assert np.abs(y[:, :4] - g[f"{kind}_{n}_cols"]).max() <= 1e-4
+
+
+def test_logmel_golden_fixture(mm, golden_dir):
+    """Stored columns of the long-utterance fixture: the CPU restatement and transformers' WhisperFeatureExtractor output."""
+    g = np.load(f"{golden_dir}/logmel.npz")
+    x = torch.from_numpy(synth("noise0.1", 480000, 99))[None].cuda()
+    for precision in ("float32", "float64"):
+        y = mm.logmel.log_mel_spectrogram(x, precision=precision).cpu().numpy()[0]
+        assert np.abs(y[:, g["cols"]] - g["oracle"]).max() <= 1e-4
+        assert np.abs(y[:, g["cols"]] - g["hf"]).max() <= 1e-4

@@ -120,6 +120,19 @@ def test_mel_tables_match_the_oracle():
     assert np.array_equal(melbank.periodic_hann(32), scipy.signal.get_window("hann", 32))
 
 
+def test_mel_bank_against_an_independent_float64_bank():
+    """The product's kaldi mel bank against transformers.audio_utils.mel_filter_bank (float64, kaldi mel scale, triangles in mel
+    space): code that shares nothing with melbank.py or the oracle.  2e-5 is the float32 rounding of the product's bank."""
+    from multi_modal_amd import melbank
+    audio_utils = pytest.importorskip("transformers.audio_utils")
+    for n_mel, n_fft, sr, lo, hi in [(128, 512, 16000, 20.0, 8000.0), (23, 512, 16000, 20.0, 8000.0), (40, 256, 8000, 0.0, 3800.0)]:
+        hf = audio_utils.mel_filter_bank(num_frequency_bins=n_fft // 2 + 1, num_mel_filters=n_mel, min_frequency=lo, max_frequency=hi,
+                                         sampling_rate=sr, norm=None, mel_scale="kaldi", triangularize_in_mel_space=True)
+        mine = torch.nn.functional.pad(melbank.kaldi_mel_banks(n_mel, n_fft, float(sr), lo, hi if hi < sr / 2 else 0.0), (0, 1)).numpy()
+        assert mine.shape == hf.T.shape
+        assert np.abs(hf.T - mine).max() <= 2e-5
+
+
 def test_dense_to_bands_round_trip():
     from multi_modal_amd import melbank
     bank = torch.nn.functional.pad(melbank.kaldi_mel_banks(128, 512, 16000.0), (0, 1)).numpy()
