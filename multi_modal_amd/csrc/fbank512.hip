@@ -31,6 +31,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 // Contraction is explicit in this file (fmaf where a fused multiply-add is meant), see fft_regs.h.
 #pragma clang fp contract(off)
@@ -126,6 +127,8 @@ struct FbankArgs {
     int n_mel;
     int vec_out;               // n_mel % 4 == 0 and a 16-byte aligned output tensor: 16-byte stores
     int chunk;                 // consecutive quads a wave takes per visit (>= 1)
+    int feat_major;            // output laid out (row, filter, frame) instead of (row, frame, filter)
+    int vec_out_fm;            // feature-major: a lane's 4 frames of one filter may go out as one 16-byte (8-byte for 16-bit types) store
     float preemph;
     float mean_scale;          // 1/win_len when the per-frame mean is removed, else 0
     LogAffine la;
@@ -519,36 +522,44 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
             for (int i = 0; i < kAccA; ++i) pa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < kAccB; ++i) pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // Operand order decides which way round the 4x4 block comes out.  Weights as operand A (row i = filter 4*blk + i, taken
+            // from lane 4*blk + i) and the spectrum as B (column q = frame slot q, from lane 4*blk + q) leave lane 4*blk + q
+            // with 4 CONSECUTIVE FILTERS of ONE frame: the time-major store.  Swapped, lane 4*blk + j holds 4 CONSECUTIVE
+            // FRAMES of ONE filter: the feature-major store.
+            auto run_mel = [&](auto swapped) {
+                constexpr bool FM = decltype(swapped)::value;
+                auto step = [&](float w, float pv, f32x4 acc) {
+                    return FM ? __builtin_amdgcn_mfma_f32_4x4x1f32(pv, w, acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_4x4x1f32(w, pv, acc, 0, 0, 0);
+                };
 #if MMFE_MEL_PAIR
 #pragma unroll
-            for (int s = 0; s < kStepsA; s += 2) {
-                const float2 pv = ld8(pa_A + s);
-                pa[s % kAccA] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[s], pv.x, pa[s % kAccA], 0, 0, 0);
-                pa[(s + 1) % kAccA] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[s + 1], pv.y, pa[(s + 1) % kAccA], 0, 0, 0);
-            }
+                for (int s = 0; s < kStepsA; s += 2) {
+                    const float2 pv = ld8(pa_A + s);
+                    pa[s % kAccA] = step(wreg[s], pv.x, pa[s % kAccA]);
+                    pa[(s + 1) % kAccA] = step(wreg[s + 1], pv.y, pa[(s + 1) % kAccA]);
+                }
 #pragma unroll
-            for (int s = 0; s < kStepsB; s += 2) {
-                const float2 pv = ld8(pa_B + s);
-                pb[s % kAccB] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[kStepsA + s], pv.x, pb[s % kAccB], 0, 0, 0);
-                pb[(s + 1) % kAccB] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[kStepsA + s + 1], pv.y, pb[(s + 1) % kAccB], 0, 0, 0);
-            }
+                for (int s = 0; s < kStepsB; s += 2) {
+                    const float2 pv = ld8(pa_B + s);
+                    pb[s % kAccB] = step(wreg[kStepsA + s], pv.x, pb[s % kAccB]);
+                    pb[(s + 1) % kAccB] = step(wreg[kStepsA + s + 1], pv.y, pb[(s + 1) % kAccB]);
+                }
 #else
 #pragma unroll
-            for (int s = 0; s < kStepsA; ++s)
-                pa[s % kAccA] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[s], pa_A[s], pa[s % kAccA], 0, 0, 0);
+                for (int s = 0; s < kStepsA; ++s) pa[s % kAccA] = step(wreg[s], pa_A[s], pa[s % kAccA]);
 #pragma unroll
-            for (int s = 0; s < kStepsB; ++s)
-                pb[s % kAccB] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[kStepsA + s], pa_B[s], pb[s % kAccB], 0, 0, 0);
+                for (int s = 0; s < kStepsB; ++s) pb[s % kAccB] = step(wreg[kStepsA + s], pa_B[s], pb[s % kAccB]);
 #endif
+            };
+            const bool fm = !WHOLE && p.feat_major != 0;        // wave-uniform
+            if (fm) run_mel(std::true_type{});
+            else run_mel(std::false_type{});
             f32x4 accA = pa[0], accB = pb[0];
 #pragma unroll
             for (int i = 1; i < kAccA; ++i) accA += pa[i];
 #pragma unroll
             for (int i = 1; i < kAccB; ++i) accB += pb[i];
-            // Operand A carries the weights (row i = filter 4*blk + i, taken from lane 4*blk + i) and operand B the
-            // spectrum (column q = frame slot q, from lane 4*blk + q), so lane 4*blk + q ends up with 4 CONSECUTIVE
-            // filters of ONE frame in registers 0..3: one 16-byte store per filter set, and the 16 lanes that share
-            // a frame write 256 contiguous bytes of its row.
+            // time-major: one 16-byte store per filter set, and the 16 lanes that share a frame write 256 contiguous bytes of its row
             MMFE_STAMP(6);
             float vab[8];
 #pragma unroll
@@ -570,7 +581,36 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
 #ifdef MMFE_ABL_NOSTORE
             if (q4 < n_ok && vab[0] == 123.456f && vab[5] == 654.321f) {
 #else
-            if (q4 < n_ok) {
+            if (fm) {
+                // lane holds filter m (and 64 + m) for frames t0 .. t0+3; a wave that takes `chunk` consecutive quads fills
+                // 16 * chunk contiguous bytes of each filter row over its visit
+                const int m = lane;
+                const int64_t fidx = ((int64_t)cur_row * p.n_mel + m) * p.out_rows + t0;
+#pragma unroll
+                for (int h = 0; h < (NGB > 0 ? 2 : 1); ++h) {
+                    if (64 * h + m >= p.n_mel || n_ok <= 0) continue;
+                    const int64_t o = fidx + (int64_t)64 * h * p.out_rows;
+                    const float* v = vab + 4 * h;
+                    if (p.out_dtype == MMFE_OUT_F32) {
+                        float* op = static_cast<float*>(p.out) + o;
+                        if (p.vec_out_fm && n_ok >= 4) MMFE_OUT_STORE4(v[0], v[1], v[2], v[3], op);
+                        else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (i < n_ok) op[i] = v[i];
+                        }
+                    } else {
+                        unsigned short* op = static_cast<unsigned short*>(p.out) + o;
+                        if (p.vec_out_fm && n_ok >= 4)
+                            *reinterpret_cast<u32x2*>(op) = u32x2{pack2_bits(v[0], v[1], p.out_dtype), pack2_bits(v[2], v[3], p.out_dtype)};
+                        else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (i < n_ok) op[i] = p.out_dtype == MMFE_OUT_F16 ? f16_bits(v[i]) : bf16_bits(v[i]);
+                        }
+                    }
+                }
+            } else if (q4 < n_ok) {
 #endif
                 if (p.out_dtype == MMFE_OUT_F32) {
                     float* orow = static_cast<float*>(p.out) + oidx;
@@ -613,8 +653,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
                 for (int i = 0; i < n; ++i) acc = fmaf(wp[16 * i], pp[i], acc);
                 const float val = apply_log_affine(acc, p.la, none_flag);
                 if (valid && m < p.n_mel) {
-                    if (p.out_dtype == MMFE_OUT_F32) static_cast<float*>(p.out)[oidx + m] = val;
-                    else static_cast<unsigned short*>(p.out)[oidx + m] = p.out_dtype == MMFE_OUT_F16 ? f16_bits(val) : bf16_bits(val);
+                    const int64_t o = p.feat_major ? ((int64_t)cur_row * p.n_mel + m) * p.out_rows + t : oidx + m;
+                    if (p.out_dtype == MMFE_OUT_F32) static_cast<float*>(p.out)[o] = val;
+                    else static_cast<unsigned short*>(p.out)[o] = p.out_dtype == MMFE_OUT_F16 ? f16_bits(val) : bf16_bits(val);
                 }
             }
         }
@@ -888,6 +929,8 @@ int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
     a.n_mel = s.n_mel;
     a.out_dtype = s.out_dtype;
     a.vec_out = (s.n_mel % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 1 : 0;
+    a.feat_major = s.layout == MMFE_LAYOUT_FEAT_MAJOR ? 1 : 0;
+    a.vec_out_fm = (out_frames % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 1 : 0;
     a.preemph = s.preemph;
     a.mean_scale = s.remove_dc ? 1.0f / (float)s.win_len : 0.0f;
     a.la = make_log_affine(s);
@@ -914,7 +957,8 @@ int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
     const int by_waves = std::max(1, (4 * MMFE_FBANK_MIN_WAVES_PER_SIMD) / kWavesPerBlock);
     int per_cu = std::min(blocks_per_cu, by_waves);
     if (plan.tune_blocks_per_cu >= 1 && plan.tune_blocks_per_cu < per_cu) per_cu = plan.tune_blocks_per_cu;
-    a.chunk = std::max(1, std::min(plan.tune_chunk > 0 ? plan.tune_chunk : kDefaultChunk, 1 << 16));
+    // feature-major rows: 8 consecutive quads per visit, so that a wave completes 128-byte lines of every filter row
+    a.chunk = std::max(1, std::min(plan.tune_chunk > 0 ? plan.tune_chunk : (a.feat_major ? 8 : kDefaultChunk), 1 << 16));
     const int64_t want = (quads + (int64_t)kWavesPerBlock * a.chunk - 1) / ((int64_t)kWavesPerBlock * a.chunk);
 
     // one load per 2-sample slice needs every frame start aligned to the slice (8 bytes of floats, 4 of PCM)
@@ -935,7 +979,7 @@ int fbank512_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
                         : launch_variant<false, 16, false, false, NGA_, NGB_, kRowsRagged>(a, want, per_cu, lds, stream);       \
         }                                                                                                                \
         const bool whole = NGA_ > 0 && frames_valid % 4 == 0 && a.vec_out && s.out_dtype == MMFE_OUT_F32 &&              \
-                           s.n_mel == (NGB_ > 0 ? 128 : 64);                                                             \
+                           s.n_mel == (NGB_ > 0 ? 128 : 64) && !a.feat_major;                                            \
         if (pcm) {                                                                                                       \
             if (na == 13 && vec2) return whole ? launch_variant<true, 13, true, true, NGA_, NGB_, kRowsWhole>(a, want, per_cu, lds, stream) \
                                                : launch_variant<true, 13, true, true, NGA_, NGB_, kRowsAny>(a, want, per_cu, lds, stream); \

@@ -274,9 +274,9 @@ int mmfe_plan_create(const mmfe_spec* spec, const void* window, const int32_t* b
 
     switch (spec->kind) {
         case MMFE_KIND_FBANK:
-            if (spec->frames_mode != MMFE_FRAMES_SNIP || spec->pad_mode != MMFE_PAD_NONE || spec->layout != MMFE_LAYOUT_TIME_MAJOR ||
+            if (spec->frames_mode != MMFE_FRAMES_SNIP || spec->pad_mode != MMFE_PAD_NONE ||
                 spec->n_mel <= 0 || spec->power != 2 || spec->spec_scale != 1.0f || spec->drop_last || spec->clamp_below_max > 0.f) {
-                set_error("FBANK: needs snip-edges framing, no padding, mel bands, power spectrum, time-major output");
+                set_error("FBANK: needs snip-edges framing, no padding, mel bands, power spectrum");
                 rc = MMFE_EINVAL;
                 break;
             }

@@ -26,11 +26,11 @@ def _fbank_plan(device: int, *, sample_frequency: float, frame_length: float, fr
                 window_type: str, blackman_coeff: float, preemphasis_coefficient: float, remove_dc_offset: bool,
                 round_to_power_of_two: bool, low_freq: float, high_freq: float, use_log_fbank: bool,
                 out_frames: int = 0, pad_value: float = 0.0, out_shift: float = 0.0, out_scale: float = 1.0,
-                out_dtype: int = N.OUT_F32, in_dtype: int = N.IN_F32) -> N.Plan:
+                out_dtype: int = N.OUT_F32, in_dtype: int = N.IN_F32, feature_major: bool = False) -> N.Plan:
     key = ("fbank", float(sample_frequency), float(frame_length), float(frame_shift), int(num_mel_bins), window_type,
            float(blackman_coeff), float(preemphasis_coefficient), bool(remove_dc_offset), bool(round_to_power_of_two),
            float(low_freq), float(high_freq), bool(use_log_fbank), int(out_frames), float(pad_value), float(out_shift),
-           float(out_scale), int(out_dtype), int(in_dtype))
+           float(out_scale), int(out_dtype), int(in_dtype), bool(feature_major))
 
     def build(dev: int) -> N.Plan:
         shift = int(sample_frequency * frame_shift * 0.001)
@@ -50,7 +50,7 @@ def _fbank_plan(device: int, *, sample_frequency: float, frame_length: float, fr
                            preemph=float(preemphasis_coefficient), power=2,
                            log_kind=N.LOG_LN_MAX if use_log_fbank else N.LOG_NONE, log_floor=_EPS,
                            out_shift=out_shift, out_scale=out_scale, out_frames=out_frames, pad_value=pad_value,
-                           layout=N.LAYOUT_TIME_MAJOR, out_dtype=out_dtype, in_dtype=in_dtype)
+                           layout=N.LAYOUT_FEAT_MAJOR if feature_major else N.LAYOUT_TIME_MAJOR, out_dtype=out_dtype, in_dtype=in_dtype)
         win = melbank.kaldi_window(window_type, size, blackman_coeff)
         return N.Plan(spec, win, bs, bl, bw, device=dev)
 
@@ -77,8 +77,10 @@ def fbank_batch(waveforms: torch.Tensor, *, out_frames: int = 0, pad_value: floa
                 frame_length: float = 25.0, frame_shift: float = 10.0, high_freq: float = 0.0, low_freq: float = 20.0,
                 num_mel_bins: int = 23, preemphasis_coefficient: float = 0.97, remove_dc_offset: bool = True,
                 round_to_power_of_two: bool = True, sample_frequency: float = 16000.0, use_log_fbank: bool = True,
-                window_type: str = "povey", dtype: torch.dtype = torch.float32, lengths=None) -> torch.Tensor:
-    """Batched form: (B, n) -> (B, m, num_mel_bins), one launch for the whole batch.  With out_frames > 0
+                window_type: str = "povey", dtype: torch.dtype = torch.float32, lengths=None,
+                feature_major: bool = False) -> torch.Tensor:
+    """Batched form: (B, n) -> (B, m, num_mel_bins), one launch for the whole batch; feature_major=True stores (B, num_mel_bins, m)
+    instead, the (frequency, time) image a patch convolution takes.  With out_frames > 0
     each clip is cut / padded (pad_value) to out_frames frames and (x + out_shift) * out_scale is applied.
     dtype=torch.float16 / torch.bfloat16 stores the float32 result rounded to nearest even (what a consumer
     under autocast would cast it to); only the power-of-two 512-point path implements it.
@@ -95,7 +97,7 @@ def fbank_batch(waveforms: torch.Tensor, *, out_frames: int = 0, pad_value: floa
                        remove_dc_offset=remove_dc_offset, round_to_power_of_two=round_to_power_of_two,
                        low_freq=low_freq, high_freq=high_freq, use_log_fbank=use_log_fbank, out_frames=out_frames,
                        pad_value=pad_value, out_shift=out_shift, out_scale=out_scale, out_dtype=OUT_CODES[dtype],
-                       in_dtype=IN_CODES[x.dtype])
+                       in_dtype=IN_CODES[x.dtype], feature_major=feature_major)
     y = run_rows(plan, x, out, lengths)
     return y if origin.type == "cuda" else y.to(origin)
 

@@ -20,8 +20,12 @@ _KW = dict(sample_frequency=SAMPLE_RATE, window_type="hanning", num_mel_bins=NUM
 
 
 def preprocessing_audio_batch(audio: torch.Tensor, out: Optional[torch.Tensor] = None,
-                              dtype: torch.dtype = torch.float32, lengths=None) -> torch.Tensor:
+                              dtype: torch.dtype = torch.float32, lengths=None, nchw: bool = False) -> torch.Tensor:
     """(B, n) or (B, 1, n) waveforms -> (B, 384, 128) normalised log-mel, one launch per batch.
+    nchw=True stores (B, 1, 128, 384) = (batch, channel, frequency, time) instead: the image layout of spectrogram encoders that
+    put frequency on the height axis, written directly in that order (`out`, when given, is (B, 128, 384)).  The reference's
+    own encoders take the time-major tensor as it is: `audio.unsqueeze(1)` (classification/vggsound/models/dynamicvit_runtime.py:110)
+    is (B, 1, 384, 128), a view of the default output.
     lengths: clips of different lengths in one batch (each row of `audio` padded to the longest); every clip is padded /
     cut to 384 frames on its own, as vggsound.py:48-56 does per sample.
     dtype=torch.float16 hands the encoder the tensor its @autocast() would cast to
@@ -34,7 +38,8 @@ def preprocessing_audio_batch(audio: torch.Tensor, out: Optional[torch.Tensor] =
         audio = audio[:, 0, :]
     if audio.dim() != 2:
         raise ValueError(f"expected (B, n) or (B, 1, n), got {tuple(audio.shape)}")
-    return fbank_batch(audio, out=out, dtype=dtype, lengths=lengths, **_KW)
+    y = fbank_batch(audio, out=out, dtype=dtype, lengths=lengths, feature_major=nchw, **_KW)
+    return y.unsqueeze(1) if nchw else y
 
 
 def preprocessing_audio(audio: torch.Tensor) -> torch.Tensor:
