@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define MMFE_ABI_VERSION 4
+#define MMFE_ABI_VERSION 5
 
 /* error codes */
 #define MMFE_OK            0
@@ -63,6 +63,15 @@ extern "C" {
 #define MMFE_KIND_LOGSPEC   2
 #define MMFE_KIND_STFT_MAG  3
 #define MMFE_KIND_FRAME     4
+#define MMFE_KIND_RESAMPLE  5  /* rational-ratio polyphase FIR resampler: rows of n samples -> rows of ceil(n * up / down) samples.
+                                  Stands where the reference resamples on the CPU before anything else happens:
+                                  librosa.load(file, sr=16000, duration=10) (classification/vggsound/dataset/vggsound.py:114) and
+                                  ffmpeg -ar 24000 (classification/recognition/dataset/extract_audio.py:6-13).
+                                  Fields: n_fft = up, hop = down (coprime), win_len = number of FIR taps (odd), `window` = the taps
+                                  (low-pass of cutoff 1/max(up, down), already multiplied by up), out_frames = 0 or the number of
+                                  output samples rows are cut / zero-padded to (duration=...), in_dtype float32 or 16-bit PCM;
+                                  every other field 0 / MMFE_*_NONE.  Alignment, output count and edge handling (zeros beyond the
+                                  row) are those of scipy.signal.resample_poly(x, up, down).  Output: (n_rows, samples), float32 */
 
 /* mmfe_spec.pad_mode: how samples outside [0, n) are read */
 #define MMFE_PAD_NONE     0    /* never read outside (snip-edges framing) */

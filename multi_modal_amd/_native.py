@@ -17,8 +17,8 @@ _lib = None
 _lib_lock = threading.Lock()
 
 # --- constants mirrored from include/mmfe.h -------------------------------------------------------
-ABI_VERSION = 4
-KIND_FBANK, KIND_LOGSPEC, KIND_STFT_MAG, KIND_FRAME = 1, 2, 3, 4
+ABI_VERSION = 5
+KIND_FBANK, KIND_LOGSPEC, KIND_STFT_MAG, KIND_FRAME, KIND_RESAMPLE = 1, 2, 3, 4, 5
 PAD_NONE, PAD_ZERO, PAD_REFLECT = 0, 1, 2
 FRAMES_SNIP, FRAMES_CENTER, FRAMES_SCIPY, FRAMES_CEIL = 0, 1, 2, 3
 LOG_NONE, LOG_LN_MAX, LOG_LN_ADD, LOG_LOG10_MAX = 0, 1, 2, 3

@@ -73,10 +73,12 @@ int validate_spec(const mmfe_spec* s) {
         set_error("mmfe_spec.struct_size is %d, this library expects %d", s->struct_size, (int)sizeof(mmfe_spec));
         return MMFE_EINVAL;
     }
-    if (s->kind < MMFE_KIND_FBANK || s->kind > MMFE_KIND_FRAME) { set_error("unknown kind %d", s->kind); return MMFE_EINVAL; }
+    if (s->kind < MMFE_KIND_FBANK || s->kind > MMFE_KIND_RESAMPLE) { set_error("unknown kind %d", s->kind); return MMFE_EINVAL; }
     if (s->hop < 1) { set_error("hop must be >= 1"); return MMFE_EINVAL; }
     if (s->win_len < 1) { set_error("win_len must be >= 1"); return MMFE_EINVAL; }
-    if (s->kind != MMFE_KIND_FRAME) {
+    if (s->kind == MMFE_KIND_RESAMPLE) {
+        if (s->n_fft < 1) { set_error("RESAMPLE: up (n_fft) must be >= 1"); return MMFE_EINVAL; }
+    } else if (s->kind != MMFE_KIND_FRAME) {
         if (s->n_fft < 2) { set_error("n_fft must be >= 2"); return MMFE_EINVAL; }
         if (s->win_off < 0 || s->win_off + s->win_len > s->n_fft) { set_error("window does not fit in n_fft"); return MMFE_EINVAL; }
         if (s->power != 1 && s->power != 2) { set_error("power must be 1 or 2"); return MMFE_EINVAL; }
@@ -88,14 +90,20 @@ int validate_spec(const mmfe_spec* s) {
     if (s->out_frames < 0) { set_error("out_frames must be >= 0"); return MMFE_EINVAL; }
     if (s->out_dtype < MMFE_OUT_F32 || s->out_dtype > MMFE_OUT_BF16) { set_error("unknown out_dtype"); return MMFE_EINVAL; }
     if (s->in_dtype != MMFE_IN_F32 && s->in_dtype != MMFE_IN_S16) { set_error("unknown in_dtype"); return MMFE_EINVAL; }
-    if (s->in_dtype != MMFE_IN_F32 && s->kind != MMFE_KIND_FBANK && s->kind != MMFE_KIND_LOGSPEC) {
-        set_error("16-bit PCM input is implemented for the FBANK and LOGSPEC kinds only");
+    if (s->in_dtype != MMFE_IN_F32 && s->kind != MMFE_KIND_FBANK && s->kind != MMFE_KIND_LOGSPEC && s->kind != MMFE_KIND_RESAMPLE) {
+        set_error("16-bit PCM input is implemented for the FBANK, LOGSPEC and RESAMPLE kinds only");
         return MMFE_EINVAL;
     }
     return MMFE_OK;
 }
 
 int out_shape(const mmfe_spec& s, int64_t n, int64_t* natural, int64_t* frames, int64_t* feat) {
+    if (s.kind == MMFE_KIND_RESAMPLE) {       // "frames" are output samples, one feature each
+        *natural = resample_out_len(s, n);
+        *frames = s.out_frames > 0 ? s.out_frames : *natural;
+        *feat = 1;
+        return MMFE_OK;
+    }
     int64_t f = 0;
     int rc = natural_frames(s, n, &f);
     if (rc) return rc;
@@ -195,6 +203,7 @@ int run_common(const Plan* plan, const RowSource& src, int64_t n_rows, int64_t n
         case IMPL_RFFT400: rc = rfft400_launch(*plan, src, n_rows, n_samples, natural, frames, out, cs, stream); break;
         case IMPL_STFT32: rc = stft32_launch(*plan, src, n_rows, n_samples, frames, out, stream); break;
         case IMPL_FRAME: rc = frame_launch(*plan, src, n_rows, n_samples, frames, out, stream); break;
+        case IMPL_RESAMPLE: rc = resample_launch(*plan, src, n_rows, n_samples, natural, frames, out, stream); break;
         default: set_error("plan has no implementation"); rc = MMFE_EINVAL;
     }
     if (rc) return rc;
@@ -252,6 +261,7 @@ int mmfe_plan_create(const mmfe_spec* spec, const void* window, const int32_t* b
     p->spec = *spec;
     p->device = device;
     p->n_bins = spec->n_fft / 2 + 1;
+    if (spec->kind == MMFE_KIND_RESAMPLE && spec->window_f64) { set_error("RESAMPLE: the taps are float32"); free_plan(p); return MMFE_EINVAL; }
     p->window.resize(spec->win_len);
     p->window64.resize(spec->win_len);
     for (int i = 0; i < spec->win_len; ++i) {
@@ -320,6 +330,10 @@ int mmfe_plan_create(const mmfe_spec* spec, const void* window, const int32_t* b
                 p->impl = IMPL_DFT_GENERIC;
                 rc = dftgen_prepare(*p);
             }
+            break;
+        case MMFE_KIND_RESAMPLE:
+            p->impl = IMPL_RESAMPLE;
+            rc = resample_prepare(*p);
             break;
         case MMFE_KIND_FRAME:
             if (spec->frames_mode != MMFE_FRAMES_CEIL) { set_error("FRAME: needs MMFE_FRAMES_CEIL"); rc = MMFE_EINVAL; break; }
@@ -404,6 +418,7 @@ const char* mmfe_plan_kernel(const mmfe_plan* plan) {
         case IMPL_DFT_GENERIC: return "dftgen";
         case IMPL_STFT32: return "stft32";
         case IMPL_FRAME: return "frame";
+        case IMPL_RESAMPLE: return "resample";
         default: return "none";
     }
 }

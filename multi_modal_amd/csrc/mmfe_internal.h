@@ -144,7 +144,7 @@ struct Plan {
     int impl = 0;                     // which kernel family serves this plan
 };
 
-enum Impl { IMPL_FBANK512 = 1, IMPL_STFT32 = 2, IMPL_DFT_GENERIC = 3, IMPL_FRAME = 4, IMPL_RFFT400 = 5 };
+enum Impl { IMPL_FBANK512 = 1, IMPL_STFT32 = 2, IMPL_DFT_GENERIC = 3, IMPL_FRAME = 4, IMPL_RFFT400 = 5, IMPL_RESAMPLE = 6 };
 
 // Where a clamp_below_max call keeps its per-row extremes (ordered-int maxima at [0, capacity), minima at
 // [capacity, 2*capacity)): the plan's own buffer, or the library's static device array (mmfe_run_noalloc).
@@ -177,6 +177,12 @@ int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64
 
 int frame_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames,
                  float* out, hipStream_t stream);
+
+// polyphase resampler (MMFE_KIND_RESAMPLE): d_window holds the [up][taps per phase] bank
+int resample_prepare(Plan& plan);
+int64_t resample_out_len(const mmfe_spec& spec, int64_t n_samples);
+int resample_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_out_natural, int64_t out_len,
+                    float* out, hipStream_t stream);
 
 // ragged batches: row r is padded from frame min(natural frames of its own length - drop_last, out_frames) on
 int fill_pad_rows_ragged(void* out, int out_dtype, int64_t n_rows, int64_t out_frames, int64_t n_feat, int layout, float value,

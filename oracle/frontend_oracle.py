@@ -293,3 +293,14 @@ def whisper_logmel(wave: np.ndarray, n_fft: int = 400, hop: int = 160, n_mels: i
     lg = np.log10(mel).T[:, :-1]
     lg = np.maximum(lg, lg.max() - 8.0)
     return ((lg + 4.0) / 4.0).astype(np.float32)
+
+
+def resample_poly(x, orig_sr: int, target_sr: int):
+    """Sample-rate conversion of the rows of `x` (float32): scipy.signal.resample_poly itself (Kaiser beta 5 low-pass,
+    zeros beyond the ends).  PINNED by construction for that function; the reference's own call is
+    librosa.load(file, sr=16000, duration=10) (classification/vggsound/dataset/vggsound.py:114), whose default resampler
+    (soxr) is a different filter design and is absent here: parity with librosa is UNPINNED."""
+    import math
+    import scipy.signal
+    g = math.gcd(int(orig_sr), int(target_sr))
+    return scipy.signal.resample_poly(np.asarray(x, dtype=np.float32), int(target_sr) // g, int(orig_sr) // g, axis=-1)

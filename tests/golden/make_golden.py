@@ -141,9 +141,27 @@ def logmel():
     print("logmel.npz max|oracle-hf| =", float(np.abs(ref - got).max()))
 
 
+def resample():
+    """Outputs of scipy.signal.resample_poly itself (float32 input): the function the resampler restates."""
+    import scipy.signal
+    out = {}
+    for tag, n, up, down in (("44k1_to_16k", 44100, 160, 441), ("48k_to_16k", 4801, 1, 3), ("48k_to_24k", 5000, 1, 2),
+                             ("16k_to_44k1", 1600, 441, 160), ("short", 7, 160, 441)):
+        x = synth("noise0.1", n, 700 + n)
+        out[tag + "_y"] = scipy.signal.resample_poly(x, up, down).astype(np.float32)
+        out[tag + "_params"] = np.array([n, 700 + n, up, down])
+    np.savez_compressed(os.path.join(HERE, "resample.npz"), **out)
+    print("resample.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        for name in sys.argv[1:]:
+            globals()[name]()
+        raise SystemExit(0)
     har()
     frame_signal()
     kaldi()
     epic()
     logmel()
+    resample()

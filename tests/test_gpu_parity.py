@@ -1033,3 +1033,104 @@ def test_vggsound_feature_major_layout(mm, dtype):
             b = mm.kaldi.fbank_batch(short, sample_frequency=16000.0, feature_major=True, **kw)
             print(kw, mm.plans.last_kernel())
             assert b.shape == (a.shape[0], a.shape[2], a.shape[1]) and torch.equal(b, a.transpose(1, 2))
+
+
+# ---- polyphase resampler (the step in front of the path: librosa.load(sr=16000) / ffmpeg -ar 24000) ----------------
+# Checker: scipy.signal.resample_poly itself (float32 rows).  Parity with librosa's own default resampler (soxr, absent
+# here) is unpinned.  Tolerance: 2e-6 abs for |x| <= 1 (float32 FIR sums of up to 60 taps per output in another order
+# than scipy's upfirdn).
+
+def test_resample_golden_scipy(mm, golden_dir):
+    import os
+    g = np.load(os.path.join(golden_dir, "resample.npz"))
+    for tag in sorted(k[:-2] for k in g.files if k.endswith("_y")):
+        n, seed, up, down = (int(v) for v in g[tag + "_params"])
+        x = synth("noise0.1", n, seed)
+        got = mm.resample_batch(torch.from_numpy(x)[None].cuda(), down, up).cpu().numpy()[0]
+        assert got.shape == g[tag + "_y"].shape
+        mx = np.abs(got - g[tag + "_y"]).max()
+        print(tag, "max", mx)
+        assert mx <= 2e-6
+
+
+@pytest.mark.parametrize("orig,target", [(44100, 16000), (48000, 16000), (48000, 24000), (22050, 16000), (16000, 44100), (8000, 16000), (44100, 24000)])
+@pytest.mark.parametrize("n", [1, 7, 440, 441, 4410, 44101])
+def test_resample_against_scipy(mm, O, orig, target, n):
+    x = np.stack([synth(k, n, 800 + i + n) for i, k in enumerate(("noise0.1", "uniform", "impulse", "dc"))])
+    ref = O.resample_poly(x, orig, target)
+    got = mm.resample_batch(torch.from_numpy(x).cuda(), orig, target).cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 2e-6
+
+
+def test_resample_load_duration_pcm_and_fixed_length(mm, O):
+    """librosa.load(sr=16000, duration=10) on a 44.1 kHz track (vggsound.py:114): 441 000 samples -> exactly 160 000; 16-bit PCM
+    rows give the bits of their decoded floats; out_samples cuts and zero-pads; strided rows and `out=`."""
+    rng = np.random.default_rng(3)
+    pcm = rng.integers(-20000, 20000, size=(3, 470000), dtype=np.int16)
+    x = pcm.astype(np.float32) / 32768.0
+    ref = O.resample_poly(x[:, :441000], 44100, 16000)
+    got_f = mm.load_resampled(torch.from_numpy(x).cuda(), 44100, sr=16000, duration=10)
+    got_p = mm.load_resampled(torch.from_numpy(pcm).cuda(), 44100, sr=16000, duration=10)
+    assert got_f.shape == (3, 160000)
+    assert np.abs(got_f.cpu().numpy() - ref).max() <= 2e-6
+    assert torch.equal(got_f, got_p)
+    one = mm.load_resampled(torch.from_numpy(x[1]), 44100, sr=16000, duration=10)       # CPU in -> CPU out, 1-D
+    assert one.device.type == "cpu" and torch.equal(one, got_f[1].cpu())
+    full = O.resample_poly(x, 44100, 16000)
+    for out_samples in (1000, 160000, full.shape[1], full.shape[1] + 777):
+        got = mm.resample_batch(torch.from_numpy(x).cuda(), 44100, 16000, out_samples=out_samples).cpu().numpy()
+        want = np.zeros((3, out_samples), np.float32)
+        k = min(out_samples, full.shape[1])
+        want[:, :k] = full[:, :k]
+        assert got.shape == want.shape and np.abs(got - want).max() <= 2e-6
+        assert np.all(got[:, k:] == 0)
+    out = torch.full((3, 160000), 7.0, device="cuda")
+    ret = mm.resample_batch(torch.from_numpy(x).cuda()[:, :441000], 44100, 16000, out=out)
+    assert ret is out and torch.equal(out, got_f)
+    with pytest.raises(ValueError):
+        mm.resample_batch(torch.from_numpy(x).cuda(), 44100, 16000, out=torch.empty(3, 5, device="cuda"))
+    same = mm.resample_batch(torch.from_numpy(pcm[:, :100]).cuda(), 16000, 16000)
+    assert torch.equal(same.cpu(), torch.from_numpy(x[:, :100]))
+
+
+def test_resample_feeds_the_fbank_path(mm, O):
+    """44.1 kHz 16-bit track -> resampler -> VGGSound features, all on the device, against the CPU chain
+    scipy.resample_poly -> oracle fbank."""
+    rng = np.random.default_rng(11)
+    pcm = (3000 * rng.standard_normal((2, 441000))).clip(-32768, 32767).astype(np.int16)
+    y = mm.load_resampled(torch.from_numpy(pcm).cuda(), 44100, sr=16000, duration=10)
+    got = mm.preprocessing_audio_batch(y).cpu().numpy()
+    ref_y = O.resample_poly(pcm.astype(np.float32) / 32768.0, 44100, 16000)
+    ref = np.stack([O.preprocessing_audio(torch.from_numpy(r)[None]).numpy() for r in ref_y])
+    assert got.shape == ref.shape == (2, 384, 128)
+    assert np.abs(got - ref).max() <= 5e-4
+
+
+def test_resample_full_size_properties(mm):
+    """512 ten-second 44.1 kHz tracks in one launch: position independence, linearity in a power of two, and the DC gain of
+    the low-pass (a constant input comes out as the same constant away from the clip ends)."""
+    g = torch.Generator(device="cuda").manual_seed(21)
+    base = (0.1 * torch.randn(4, 441000, device="cuda", generator=g)).clamp_(-1, 1)
+    small = mm.resample_batch(base, 44100, 16000)
+    big = mm.resample_batch(base.repeat(128, 1), 44100, 16000)
+    assert big.shape == (512, 160000)
+    assert torch.equal(big.view(128, 4, 160000), small.unsqueeze(0).expand(128, -1, -1))
+    assert torch.equal(mm.resample_batch(base * 0.25, 44100, 16000), small * 0.25)
+    dc = mm.resample_batch(torch.full((1, 441000), 0.5, device="cuda"), 44100, 16000)
+    assert (dc[0, 100:-100] - 0.5).abs().max().item() <= 2e-4
+    assert torch.isfinite(big).all()
+
+
+def test_resample_rejects_bad_plans(mm):
+    from multi_modal_amd import _native as N
+    taps = mm.resample.lowpass_taps(160, 441)
+    with pytest.raises(mm.MmfeError, match="coprime"):
+        N.Plan(N.make_spec(kind=N.KIND_RESAMPLE, n_fft=320, hop=882, win_len=len(taps)), taps, device=0)
+    with pytest.raises(mm.MmfeError, match="odd"):
+        N.Plan(N.make_spec(kind=N.KIND_RESAMPLE, n_fft=160, hop=441, win_len=len(taps) - 1), taps[:-1], device=0)
+    with pytest.raises(mm.MmfeError, match="mel|log"):
+        N.Plan(N.make_spec(kind=N.KIND_RESAMPLE, n_fft=160, hop=441, win_len=len(taps), log_kind=N.LOG_LN_MAX), taps, device=0)
+    plan = N.Plan(N.make_spec(kind=N.KIND_RESAMPLE, n_fft=160, hop=441, win_len=len(taps)), taps, device=0)
+    assert plan.kernel == "resample"
+    plan.close()

@@ -276,3 +276,23 @@ def test_bench_cpu_baseline_fields():
     assert r["cores"] == 4 and r["value"] == r["legs"]["4_workers"]["value"]       # the leg the reference's DataLoader corresponds to
     assert 1 <= bench.host_core_share() <= 16
     assert set(bench.CONFIGS) == {"vgg4096", "vgg200k", "logmel"}
+
+
+def test_resampler_taps_and_output_lengths(N):
+    """The low-pass the resampler uploads is the one scipy.signal.resample_poly designs for float32 rows, and the output
+    length rule is scipy's ceil(n * up / down)."""
+    import scipy.signal
+    from multi_modal_amd import resample
+    for up, down in [(160, 441), (1, 3), (1, 2), (441, 160), (2, 1), (3, 7)]:
+        m = max(up, down)
+        h = scipy.signal.firwin(20 * m + 1, 1.0 / m, window=("kaiser", 5.0)).astype(np.float32)
+        h *= up
+        assert np.array_equal(resample.lowpass_taps(up, down), h)
+        spec = N.make_spec(kind=N.KIND_RESAMPLE, n_fft=up, hop=down, win_len=20 * m + 1)
+        for n in [1, 7, 440, 441, 442, 44100, 441000]:
+            assert N.spec_out_shape(spec, n) == (-(-n * up // down), 1)
+        spec = N.make_spec(kind=N.KIND_RESAMPLE, n_fft=up, hop=down, win_len=20 * m + 1, out_frames=160000)
+        assert N.spec_out_shape(spec, 441000) == (160000, 1)
+    assert resample._ratio(44100, 16000) == (160, 441) and resample._ratio(48000, 24000) == (1, 2)
+    with pytest.raises(ValueError):
+        resample._ratio(0, 16000)
