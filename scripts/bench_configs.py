@@ -2,7 +2,7 @@
 """Throughput of the secondary configurations (BASELINE.json configs[2], the EPIC parity configuration,
 configs[4] per GPU and the headline configuration fed with 16-bit PCM) on one GPU: units/s, achieved algorithmic GB/s and fraction of the 8 TB/s HBM peak.
 
-    python scripts/bench_configs.py [har] [epic] [logmel] [pcm] [--iters 20]
+    python scripts/bench_configs.py [har] [epic] [logmel] [pcm] [resample] [--iters 20]
 
 bench.py imports `run_config` to append the same lines to its JSON under "secondary".
 """
@@ -70,12 +70,19 @@ def run_config(name: str, dev: torch.device, iters: int = 20) -> dict:
         avg, mn = timeit(lambda: mm.preprocessing_audio_batch(x, out=out), iters)
         return _line("VGGSound log-mel from 16-bit PCM (4096, 160000) int16 -> (4096, 384, 128), kernel " + mm.plans.last_kernel(),
                      "clips/s", B, 153600 * 2 + 384 * 128 * 4, avg, mn)
+    if name == "resample":
+        B = 1024
+        x = (0.1 * torch.randn(B, 441000, device=dev, generator=g)).clamp_(-1, 1).mul_(32767.0).round_().to(torch.int16)
+        out = torch.empty(B, 160000, device=dev)
+        avg, mn = timeit(lambda: mm.resample_batch(x, 44100, 16000, out=out), iters)
+        return _line("resampler 44.1 -> 16 kHz from 16-bit PCM (1024, 441000) int16 -> (1024, 160000), kernel resample",
+                     "clips/s", B, 441000 * 2 + 160000 * 4, avg, mn)
     raise ValueError(name)
 
 
 def main():
     iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 20
-    names = ("har", "epic", "logmel", "pcm")
+    names = ("har", "epic", "logmel", "pcm", "resample")
     which = [a for a in sys.argv[1:] if a in names] or list(names)
     dev = torch.device("cuda", 0)
     for name in which:
