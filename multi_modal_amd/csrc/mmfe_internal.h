@@ -139,8 +139,10 @@ struct Plan {
     float* d_band_w = nullptr;
     float* d_rowmax = nullptr;        // scratch for clamp_below_max: per-row maxima [0, capacity) and minima [capacity, 2*capacity)
     int64_t rowmax_capacity = 0;
-    int tune_blocks_per_cu = 0;       // > 0: upper limit on resident blocks per CU (tuning; read from the environment at plan creation)
-    int tune_chunk = 0;               // > 0: consecutive frame quads a wave takes per visit (tuning, as above)
+    // tuning overrides, read from the environment once at plan creation (0 = the kernel's own choice)
+    int tune_blocks_per_cu = 0;       // n_fft 512 kernel: upper limit on resident blocks per CU; STFT-32 kernel: rows per group
+    int tune_chunk = 0;               // n_fft 512 kernel: consecutive frame quads a wave takes per visit; STFT-32 kernel: mover waves (-1: phase-serial form)
+    int tune_nt = 1;                  // STFT-32 kernel: output stores bypass the caches
     int impl = 0;                     // which kernel family serves this plan
 };
 

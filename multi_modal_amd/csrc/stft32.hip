@@ -11,6 +11,13 @@
 // registers, and writes its 17 magnitudes into an LDS image of the group's output block.  That
 // block is contiguous in global memory, so it is drained with 16-byte coalesced stores: the kernel
 // is bound by HBM writes (81 % of its traffic), and partial-line stores would waste them.
+//
+// Two kernels share that arithmetic.  stft32_ws_kernel (aligned, contiguous batches: the regular case) splits the
+// waves of a block by role: compute waves turn the staged rows of group g into the output image of group g while a
+// few mover waves store the image of group g - 1 and stage the samples of group g + 1, both buffers doubled in LDS,
+// one barrier per group.  A wave that waits for the memory system to accept its stores then never holds up
+// arithmetic, and the stores of a CU leave as one steady stream.  stft32_kernel (any alignment, slices) runs the
+// phases one after the other with every wave taking part in each.
 #include "mmfe_internal.h"
 #include "fft_regs.h"
 
@@ -37,6 +44,8 @@ struct StftArgs {
     int power;           // 1 = magnitude, 2 = power
     int vec_in;          // rows are contiguous, 16-byte aligned and n_samples % 4 == 0: stage with 16-byte loads
     int vec_out;         // every group's output block starts 16-byte aligned: drain with 16-byte stores
+    int mover_waves;     // stft32_ws_kernel: the last `mover_waves` waves of a block store and stage, the others compute
+    unsigned inv_frames; // ceil(2^32 / n_frames): (f * inv_frames) >> 32 == f / n_frames for the frame indices of a group
     float win[kN];       // window pre-multiplied by 0.5 * spec_scale
 };
 
@@ -48,6 +57,42 @@ __device__ __forceinline__ float2 tw32(int k) {
 }
 
 constexpr int kPrefetch = 4;     // float4 registers per thread for the next group's samples
+
+// One frame: 32 samples at xp (LDS) -> 17 magnitudes (or powers) at o[k * S] (LDS image of the output block).
+template <bool ALIGNED_HOP>
+__device__ __forceinline__ void stft32_frame(const StftArgs& p, const float* xp, float* o, int S) {
+    float x[32];
+    if (ALIGNED_HOP) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(xp + 4 * q);
+            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < 32; ++n) x[n] = xp[n];
+    }
+    float2 z[16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) z[n] = make_float2(x[2 * n] * p.win[2 * n], x[2 * n + 1] * p.win[2 * n + 1]);
+    fft16(z);
+#pragma unroll
+    for (int k = 0; k <= 8; ++k) {
+        const float2 zk = z[fft16_pos(k)];
+        const float2 zp = z[fft16_pos((16 - k) & 15)];
+        const float2 tw = tw32(k);
+        const float2 E = make_float2(zk.x + zp.x, zk.y - zp.y);
+        const float2 D = make_float2(zk.x - zp.x, zk.y + zp.y);
+        const float2 G = cmul(tw, D);
+        const float2 xa = cadd(E, G), xb = csub(E, G);
+        float pa = xa.x * xa.x + xa.y * xa.y;
+        float pb = xb.x * xb.x + xb.y * xb.y;
+        if (p.power == 1) { pa = __builtin_amdgcn_sqrtf(pa); pb = __builtin_amdgcn_sqrtf(pb); }
+        o[k * S] = pa;
+        if (k != 8) o[(16 - k) * S] = pb;
+    }
+}
+
 
 // One group = R consecutive rows, three phases:
 //   stage  the group's samples (prefetched into registers two groups ahead, coalesced 16-byte reads) are
@@ -132,38 +177,7 @@ __global__ void __launch_bounds__(kMaxThreads) stft32_kernel(const StftArgs p) {
         for (int f = threadIdx.x; f < n_fr; f += nthr) {
             const int r = f / S;
             const int s = f - r * S;
-            const float* xp = s_in + r * p.row_lds + s * p.hop;    // frame s covers samples [s*hop-16, s*hop+16)
-            float x[32];
-            if (ALIGNED_HOP) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float4 v = *reinterpret_cast<const float4*>(xp + 4 * q);
-                    x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
-                }
-            } else {
-#pragma unroll
-                for (int n = 0; n < 32; ++n) x[n] = xp[n];
-            }
-            float2 z[16];
-#pragma unroll
-            for (int n = 0; n < 16; ++n) z[n] = make_float2(x[2 * n] * p.win[2 * n], x[2 * n + 1] * p.win[2 * n + 1]);
-            fft16(z);
-            float* o = s_out + r * 17 * S + s;
-#pragma unroll
-            for (int k = 0; k <= 8; ++k) {
-                const float2 zk = z[fft16_pos(k)];
-                const float2 zp = z[fft16_pos((16 - k) & 15)];
-                const float2 tw = tw32(k);
-                const float2 E = make_float2(zk.x + zp.x, zk.y - zp.y);
-                const float2 D = make_float2(zk.x - zp.x, zk.y + zp.y);
-                const float2 G = cmul(tw, D);
-                const float2 xa = cadd(E, G), xb = csub(E, G);
-                float pa = xa.x * xa.x + xa.y * xa.y;
-                float pb = xb.x * xb.x + xb.y * xb.y;
-                if (p.power == 1) { pa = __builtin_amdgcn_sqrtf(pa); pb = __builtin_amdgcn_sqrtf(pb); }
-                o[k * S] = pa;
-                if (k != 8) o[(16 - k) * S] = pb;
-            }
+            stft32_frame<ALIGNED_HOP>(p, s_in + r * p.row_lds + s * p.hop, s_out + r * 17 * S + s, S);    // frame s covers samples [s*hop-16, s*hop+16)
         }
         lds_barrier();      // output image complete; every wave is done reading s_in
         // ---- stage the next group (its loads were issued a whole work phase ago), refill the prefetch --------
@@ -187,6 +201,115 @@ __global__ void __launch_bounds__(kMaxThreads) stft32_kernel(const StftArgs p) {
     }
 }
 
+constexpr int kWsPrefetch = 6;   // float4 registers per mover lane for the samples of the group after next
+
+// Wave-specialised form (rows contiguous and 16-byte aligned, hop a multiple of 4, group output blocks 16-byte aligned).
+// LDS holds two input buffers and two output images.  In step t a block's compute waves work on its t-th group
+// (input buffer t & 1 -> image t & 1) while its mover waves store image (t - 1) & 1, drop the samples of group t + 1
+// (requested one step earlier) into input buffer (t + 1) & 1 and request those of group t + 2; one barrier ends the step.
+template <bool NT>
+__global__ void __launch_bounds__(kMaxThreads) stft32_ws_kernel(const StftArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    const int R = p.rows_per_block;
+    const int S = p.n_frames;
+    const int T = p.n_samples;
+    const int T4 = T >> 2;
+    const int in_floats = R * p.row_lds;
+    const int out_floats = R * 17 * S;
+    float* s_in0 = reinterpret_cast<float*>(smem);                   // 2 * R * row_lds
+    float* s_out0 = s_in0 + 2 * in_floats;                           // 2 * R * 17 * S
+    const int n_groups = (p.n_rows + R - 1) / R;
+    const int n_compute = blockDim.x - 64 * p.mover_waves;           // threads that compute
+    const int n_mover = 64 * p.mover_waves;
+    const bool mover = (int)threadIdx.x >= n_compute;
+    const int ml = (int)threadIdx.x - n_compute;                     // mover lane index
+    const float* gin = static_cast<const float*>(p.src.base);
+
+    for (int i = threadIdx.x; i < 2 * R * (p.row_lds - T); i += blockDim.x) {   // zero margins of both input buffers: never overwritten
+        const int r = i / (p.row_lds - T);
+        int j = i - r * (p.row_lds - T);
+        j = j < 16 ? j : j + T;
+        s_in0[r * p.row_lds + j] = 0.f;
+    }
+
+    vf4 pf[kWsPrefetch];
+    auto fetch = [&](int grp) {                                      // movers: request group grp's samples
+        const int row0 = grp * R;
+        const int rows = min(R, p.n_rows - row0);
+        const vf4* g4 = reinterpret_cast<const vf4*>(gin + (int64_t)row0 * T);
+#pragma unroll
+        for (int q = 0; q < kWsPrefetch; ++q) {
+            const int i = ml + q * n_mover;
+            pf[q] = (grp < n_groups && i < rows * T4) ? __builtin_nontemporal_load(g4 + i) : vf4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stage = [&](int grp, float* s_in) {                         // movers: registers -> LDS rows
+        if (grp >= n_groups) return;
+        const int rows = min(R, p.n_rows - grp * R);
+#pragma unroll
+        for (int q = 0; q < kWsPrefetch; ++q) {
+            const int i = ml + q * n_mover;
+            if (i < rows * T4) {
+                const int r = i / T4;
+                const int j4 = i - r * T4;
+                *reinterpret_cast<vf4*>(s_in + r * p.row_lds + 16 + 4 * j4) = pf[q];
+            }
+        }
+    };
+    if (mover) {
+        fetch(blockIdx.x);
+        stage(blockIdx.x, s_in0);
+        fetch(blockIdx.x + gridDim.x);
+    }
+    lds_barrier();
+
+    // one step beyond the block's last group: the movers store its image
+    for (int grp = blockIdx.x, t = 0; grp - (int)gridDim.x < n_groups; grp += gridDim.x, ++t) {
+        if (!mover) {
+            if (grp < n_groups) {
+                const int rows = min(R, p.n_rows - grp * R);
+                const float* s_in = s_in0 + (t & 1) * in_floats;
+                float* s_out = s_out0 + (t & 1) * out_floats;
+                const int n_fr = rows * S;
+                for (int f = threadIdx.x; f < n_fr; f += n_compute) {
+                    const int r = (int)__umulhi((unsigned)f, p.inv_frames);
+                    const int fs = f - r * S;
+                    stft32_frame<true>(p, s_in + r * p.row_lds + fs * p.hop, s_out + r * 17 * S + fs, S);
+                }
+            }
+        } else {
+            if (t > 0) {                                              // store the previous group's image
+                const int prev = grp - (int)gridDim.x;
+                const int rows = min(R, p.n_rows - prev * R);
+                const int n_out = rows * 17 * S;
+                const float* s_out = s_out0 + ((t - 1) & 1) * out_floats;
+                float* gout = p.out + (int64_t)prev * R * 17 * S;
+                const int n4 = n_out >> 2;
+                vf4* g4 = reinterpret_cast<vf4*>(gout);
+                const vf4* l4 = reinterpret_cast<const vf4*>(s_out);
+                int i = ml;
+                for (; i + 3 * n_mover < n4; i += 4 * n_mover) {      // four 16-byte LDS reads in flight per lane
+                    const vf4 a = l4[i], b = l4[i + n_mover], c = l4[i + 2 * n_mover], d = l4[i + 3 * n_mover];
+                    if (NT) {
+                        __builtin_nontemporal_store(a, g4 + i);
+                        __builtin_nontemporal_store(b, g4 + i + n_mover);
+                        __builtin_nontemporal_store(c, g4 + i + 2 * n_mover);
+                        __builtin_nontemporal_store(d, g4 + i + 3 * n_mover);
+                    } else {
+                        g4[i] = a; g4[i + n_mover] = b; g4[i + 2 * n_mover] = c; g4[i + 3 * n_mover] = d;
+                    }
+                }
+                for (; i < n4; i += n_mover) { if (NT) __builtin_nontemporal_store(l4[i], g4 + i); else g4[i] = l4[i]; }
+                for (int j = 4 * n4 + ml; j < n_out; j += n_mover) gout[j] = s_out[j];
+            }
+            stage(grp + gridDim.x, s_in0 + ((t + 1) & 1) * in_floats);
+            fetch(grp + 2 * gridDim.x);
+        }
+        lds_barrier();
+    }
+}
+
 }  // namespace
 
 int stft32_prepare(Plan& plan) {
@@ -199,6 +322,10 @@ int stft32_prepare(Plan& plan) {
                   "output, no mel/log/affine/clamp, natural frame count");
         return MMFE_EINVAL;
     }
+    // tuning knobs, read once per plan: rows per group of the wave-specialised form, its mover waves (-1: phase-serial form)
+    if (const char* e = std::getenv("MMFE_STFT_ROWS")) plan.tune_blocks_per_cu = std::atoi(e);
+    if (const char* e = std::getenv("MMFE_STFT_MOVERS")) plan.tune_chunk = std::atoi(e);
+    if (const char* e = std::getenv("MMFE_STFT_NT")) plan.tune_nt = std::atoi(e);              // 0: cached output stores
     return MMFE_OK;
 }
 
@@ -222,26 +349,52 @@ int stft32_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
     // LDS row: 16 leading zeros + samples + zeros up to the end of the last frame
     const int need = (int)((n_frames - 1) * s.hop + kN);
     a.row_lds = (std::max(need, (int)n_samples + 16) + 3) & ~3;
-    // rows per group R: a multiple of 4 keeps every group's output block 16-byte aligned.  The kernel is bound
-    // by its output stores, and the largest group that fits LDS measured fastest (fewest barriers per byte;
-    // lane efficiency of the last pass over the frames matters less), one block per CU.
     const int64_t per_row_bytes = ((int64_t)a.row_lds + 17 * n_frames) * 4;
+    const bool contiguous = src.offsets == nullptr && src.stride == n_samples && n_samples % 4 == 0 &&
+                            reinterpret_cast<uintptr_t>(src.base) % 16 == 0;
+    const bool aligned_hop = s.hop % 4 == 0;
+    a.inv_frames = (unsigned)(((uint64_t)1 << 32) / (uint64_t)n_frames + 1);
+    int blocks_per_cu = 1, cus = 256;
+
+    // ---- wave-specialised form: two input buffers + two output images in LDS -------------------------------------
+    // R: the largest multiple of 4 (16-byte aligned output blocks) whose doubled buffers fit; the compute waves cover a
+    // group's R * S frames in as few passes as 16 - movers waves allow, the movers' prefetch registers must hold a group.
+    if (contiguous && aligned_hop && reinterpret_cast<uintptr_t>(out) % 16 == 0 && n_rows < ((int64_t)1 << 30) && plan.tune_chunk >= 0) {
+        int r_ws = (int)std::min<int64_t>(64, (150 * 1024) / (2 * per_row_bytes)) & ~3;
+        if (plan.tune_blocks_per_cu >= 4 && plan.tune_blocks_per_cu % 4 == 0 && plan.tune_blocks_per_cu < r_ws) r_ws = plan.tune_blocks_per_cu;
+        if (r_ws >= 4 && n_frames >= 2 && (int64_t)r_ws * n_frames < 65536) {     // (the reciprocal division needs 2 <= S, R * S < 2^16)
+            const int pass_waves = (int)(((int64_t)r_ws * n_frames + 63) / 64);       // compute waves for one pass
+            int movers = pass_waves <= 12 ? 4 : (pass_waves == 13 ? 3 : (pass_waves == 14 ? 2 : 4));
+            if (plan.tune_chunk >= 1 && plan.tune_chunk <= 8) movers = plan.tune_chunk;
+            const int compute = std::min(pass_waves, 16 - movers);
+            if ((int64_t)r_ws * (n_samples / 4) <= (int64_t)kWsPrefetch * 64 * movers) {
+                a.rows_per_block = r_ws;
+                a.mover_waves = movers;
+                a.vec_in = a.vec_out = 1;
+                const int threads = 64 * (compute + movers);
+                const size_t lds = (size_t)(2 * r_ws * per_row_bytes);
+                const bool nt = plan.tune_nt != 0;
+                const void* fn = nt ? reinterpret_cast<const void*>(&stft32_ws_kernel<true>) : reinterpret_cast<const void*>(&stft32_ws_kernel<false>);
+                const int rc = kernel_prepare(fn, threads, lds, &blocks_per_cu, &cus);
+                if (rc) return rc;
+                const int64_t groups = (n_rows + r_ws - 1) / r_ws;
+                const int grid = (int)std::min<int64_t>(groups, (int64_t)cus * blocks_per_cu);
+                if (nt) hipLaunchKernelGGL(stft32_ws_kernel<true>, dim3(grid), dim3(threads), lds, stream, a);
+                else hipLaunchKernelGGL(stft32_ws_kernel<false>, dim3(grid), dim3(threads), lds, stream, a);
+                MMFE_HIP_CHECK(hipGetLastError());
+                return MMFE_OK;
+            }
+        }
+    }
+
+    // ---- phase-serial form ------------------------------------------------------------------------------------------
+    // rows per group R: a multiple of 4 keeps every group's output block 16-byte aligned; the largest group that fits LDS
+    // measured fastest (fewest barriers per byte), one block per CU.
     int best_r = 0, best_threads = 0;
     for (int r = 4; r <= 64; r += 4) {
         if (r * per_row_bytes > 144 * 1024) break;
         best_r = r;
         best_threads = (int)std::min<int64_t>(kMaxThreads, ((int64_t)r * n_frames + 63) / 64 * 64);
-    }
-    if (const char* force = std::getenv("MMFE_STFT_ROWS")) {   // tuning override: rows per group
-        const int r = std::atoi(force);
-        if (r >= 4 && r % 4 == 0 && r * per_row_bytes <= 150 * 1024) {
-            best_r = r;
-            best_threads = (int)std::min<int64_t>(kMaxThreads, ((int64_t)r * n_frames + 63) / 64 * 64);
-        }
-    }
-    if (const char* force = std::getenv("MMFE_STFT_THREADS")) {   // tuning override: block size
-        const int t = std::atoi(force);
-        if (t >= 64 && t <= kMaxThreads && t % 64 == 0) best_threads = t;
     }
     if (best_r == 0) {   // very long rows: one row per group, frames looped over the block
         best_r = 1;
@@ -252,15 +405,12 @@ int stft32_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
         }
     }
     a.rows_per_block = best_r;
-    a.vec_in = (src.offsets == nullptr && src.stride == n_samples && n_samples % 4 == 0 &&
-                reinterpret_cast<uintptr_t>(src.base) % 16 == 0) ? 1 : 0;
+    a.vec_in = contiguous ? 1 : 0;
     a.vec_out = (((int64_t)best_r * 17 * n_frames) % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 1 : 0;
     const size_t lds = (size_t)best_r * per_row_bytes;
     const int64_t groups = (n_rows + best_r - 1) / best_r;
-    const bool aligned_hop = s.hop % 4 == 0;
     const void* fn = aligned_hop ? reinterpret_cast<const void*>(&stft32_kernel<true>) : reinterpret_cast<const void*>(&stft32_kernel<false>);
     // persistent blocks: exactly as many as are resident at once (registers, LDS and wave slots all count)
-    int blocks_per_cu = 1, cus = 256;
     const int rc = kernel_prepare(fn, best_threads, lds, &blocks_per_cu, &cus);
     if (rc) return rc;
     const int grid = (int)std::min<int64_t>(groups, (int64_t)cus * blocks_per_cu);

@@ -27,6 +27,8 @@ def timeit(fn, iters, warmup=3):
         e.record()
     torch.cuda.synchronize()
     ms = sorted(s.elapsed_time(e) for s, e in ev)
+    if os.environ.get("MMFE_BENCH_VERBOSE"):
+        print("sorted ms:", " ".join(f"{m:.3f}" for m in ms), file=sys.stderr)
     return sum(ms) / len(ms), ms[0]
 
 

@@ -388,6 +388,21 @@ def test_har_stft_mag(mm, O, shape):
     assert np.abs(got - ref).max() <= 1e-6
 
 
+def test_har_many_groups_per_block(mm, O):
+    """More row groups than resident blocks, a last group that is not full and a row count that is not a multiple of 4: every
+    block of the wave-specialised STFT kernel alternates between its two LDS buffer sets several times and ends on a partial
+    group; the phase-serial kernel (rows that are not 16-byte aligned) must give the same bits."""
+    g = np.random.default_rng(77)
+    x = g.standard_normal((12301, 192)).astype(np.float32)
+    ref = O.stft_mag(x)
+    got = mm.stft_mag(torch.from_numpy(x).cuda())
+    assert got.shape == ref.shape
+    assert np.abs(got.cpu().numpy() - ref).max() <= 1e-6
+    shifted = torch.empty(12301 * 192 + 1, device="cuda")[1:].view(12301, 192)      # 4-byte aligned only
+    shifted.copy_(torch.from_numpy(x))
+    assert torch.equal(mm.stft_mag(shifted), got)
+
+
 def test_har_against_scipy(mm):
     import scipy.signal
     rng = np.random.default_rng(11)
