@@ -52,6 +52,16 @@ constexpr int kPGuard = 8;                          // floats in front of bin 0 
 constexpr int kTwBytes = 25 * 16 * 8;               // W400^(b*c) table, [c][b]
 constexpr int kStreams = 4;
 
+#ifndef MMFE_R400_DIRECT
+#define MMFE_R400_DIRECT 1      // 1: every lane loads its own strided samples (n = 16a + b of frames A and B) straight from global memory, one
+                                //    pass ahead; the 2.5x overlap of neighbouring frames is served by L1/L2.  0: the wave's samples are staged in LDS
+                                //    by 16-byte loads and gathered from there
+#endif
+#ifndef MMFE_R400_HALFPARK
+#define MMFE_R400_HALFPARK 1    // 1: a lane separates the bins k <= 200 of its own FFT columns, Z[k] from registers; only Z[201..399] is parked
+                                //    in LDS for the partners Z[400 - k].  0: all of Z is parked in natural order and both members are read back
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Rfft400Args {
@@ -157,6 +167,18 @@ __device__ __forceinline__ float4 load4(const int16_t* sp) {
                        (float)(int16_t)(r.y & 0xffffu) * k, (float)((int32_t)r.y >> 16) * k);
 }
 
+// Stored element i of a row of n under the plan's padding rule (i may lie outside the row), undecoded.
+template <typename S>
+__device__ __forceinline__ S fetch_raw(const S* row, int i, int n, int pad_mode) {
+    if (i >= 0 && i < n) return row[i];
+    if (n <= 0 || pad_mode != MMFE_PAD_REFLECT) return S(0);
+    if (n == 1) return row[0];
+    const int period = 2 * (n - 1);
+    int m = i % period;
+    if (m < 0) m += period;
+    return row[m < n ? m : period - m];
+}
+
 template <typename SMP /* input element: float or int16_t PCM */, int HOP /* 160: specialised staging layout; 0: any hop <= 160 */,
           bool VEC /* row starts aligned to 4 samples and hop % 4 == 0 */,
           int S0, int S1, int S2, int S3 /* bins walked by the four mel instruction streams */, bool SPLIT /* last stream: runs split in two halves */>
@@ -214,6 +236,32 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
         if (o >= opr) { o -= opr; r += 1; }
     };
 
+#if MMFE_R400_DIRECT
+    // the samples of the lane's two frames under octet (r, o): n = 16a + b of frame A = 2*pr and of frame B = A + 1
+    // (kept as loaded; 16-bit PCM is decoded where the values are used, so that nothing waits for the loads here)
+    SMP ga[25], gb[25];
+    auto fetch = [&](unsigned r, unsigned o) {
+        const unsigned rr = r < (unsigned)p.n_rows ? r : 0;
+        const SMP* rp = row_ptr_as<SMP>(p.src, rr);
+        const int n_row = row_samples(p.src, rr, p.n_samples);
+        const int first = (int)o * 8 * hop + p.shift;
+        const bool interior = first >= 0 && first + 7 * hop + kN <= n_row;     // wave-uniform
+        const int ia = first + 2 * pr * hop + b;
+        if (interior) {
+            const SMP* qa = rp + ia;
+            const SMP* qb = qa + hop;
+#pragma unroll
+            for (int a = 0; a < 25; ++a) { ga[a] = qa[16 * a]; gb[a] = qb[16 * a]; }
+        } else {    // the octet touches an end of the row: padding rule per sample
+#pragma unroll
+            for (int a = 0; a < 25; ++a) {
+                ga[a] = fetch_raw(rp, ia + 16 * a, n_row, p.pad_mode);
+                gb[a] = fetch_raw(rp, ia + hop + 16 * a, n_row, p.pad_mode);
+            }
+        }
+    };
+    fetch(row, oq);
+#else
     // the samples under octet (r, o): lane holds pieces lane, lane+64, ... of 4 consecutive samples
     float4 pf[kPF];
     auto fetch = [&](unsigned r, unsigned o) {
@@ -245,6 +293,7 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
     // sample n = 16a + b of frames A = 2*pr and B = 2*pr + 1 in the staging buffer
     const float* st_a = stage + stage_pos<HOP>(2 * pr * hop) + b;
     const float* st_b = HOP == 160 ? st_a + 160 : stage + (2 * pr + 1) * hop + b;
+#endif
     float* const pw_a = parea + (2 * pr) * kPS + kPGuard;
     float* const pw_b = pw_a + kPS;
 
@@ -256,6 +305,11 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
         const int t0 = (int)oq * 8;          // first frame of the octet
         const unsigned cur_row = row;
 
+#if MMFE_R400_DIRECT
+        float2 z[25];
+#pragma unroll
+        for (int a = 0; a < 25; ++a) z[a] = make_float2(win[a] * sample_value(ga[a]), win[a] * sample_value(gb[a]));
+#else
         // ---- stage the wave's samples -----------------------------------------------------------
 #pragma unroll
         for (int q = 0; q < kPF; ++q) {
@@ -272,6 +326,8 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
             z[a] = make_float2(win[a] * st_a[off_a], win[a] * st_b[off_b]);
         }
         wave_lds_fence();
+
+#endif
 
         MMFE_STAMP(1);
         // ---- next octet's samples: in flight under the rest of this pass ----------------------------
@@ -315,6 +371,53 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
         wave_lds_fence();
 
         MMFE_STAMP(3);
+#if MMFE_R400_HALFPARK
+        // ---- second half: 16-point FFTs of columns b and b+16 leave Z[c + 25 d] in registers.  The two real spectra separate
+        //      from the pairs (k, 400 - k), k <= 200: the lane owns k = c + 25 d for d <= 7 (and k = 200 = column 0, d = 8); the
+        //      partners 400 - k > 200 are the d >= 8 half of some column, which is all that goes to LDS -------------------------
+        fft16(u0);
+        fft16(u1);
+#pragma unroll
+        for (int d = 8; d < 16; ++d) tile[b + 25 * d] = u0[fft16_pos(d)];
+        if (b <= 8) {
+#pragma unroll
+            for (int d = 8; d < 16; ++d) tile[16 + b + 25 * d] = u1[fft16_pos(d)];
+        }
+        if (b == 0) tile[400] = u0[fft16_pos(0)];      // k = 0 pairs with itself; k = 200 finds itself at 400 - 200 (written above)
+        wave_lds_fence();
+
+        MMFE_STAMP(4);
+        float p_a[17], p_b[17];
+#pragma unroll
+        for (int i = 0; i < 17; ++i) {
+            // i < 9: column b, d = i (d = 8 is bin 200 + b: a real bin for b = 0 only); i >= 9: column 16 + b, d = i - 9 (b <= 8 only)
+            const int k = i < 9 ? b + 25 * i : 16 + b + 25 * (i - 9);
+            const float2 zk = i < 9 ? u0[fft16_pos(i)] : u1[fft16_pos(i - 9)];
+            const float2 zm = tile[400 - k];
+            const float2 E = make_float2(zk.x + zm.x, zk.y - zm.y);     // X_A[k]
+            const float2 D = make_float2(zk.x - zm.x, zk.y + zm.y);     // i * X_B[k]
+            p_a[i] = E.x * E.x + E.y * E.y;
+            p_b[i] = D.x * D.x + D.y * D.y;
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            pw_a[b + 25 * i] = p_a[i];
+            pw_b[b + 25 * i] = p_b[i];
+        }
+        if (b == 0) {
+            pw_a[200] = p_a[8];
+            pw_b[200] = p_b[8];
+        }
+        if (b <= 8) {
+#pragma unroll
+            for (int i = 9; i < 17; ++i) {
+                pw_a[16 + b + 25 * (i - 9)] = p_a[i];
+                pw_b[16 + b + 25 * (i - 9)] = p_b[i];
+            }
+        }
+        wave_lds_fence();
+#else
         // ---- second half: 16-point FFTs of columns b and b+16; Z[c + 25 d] parked in natural order ----
         fft16(u0);
         fft16(u1);
@@ -353,6 +456,8 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
             pw_b[192 + b] = p_b[12];
         }
         wave_lds_fence();
+
+#endif
 
         MMFE_STAMP(5);
         // ---- banded mel on the matrix pipe, log, affine, store ---------------------------------------
@@ -393,6 +498,9 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
                 }
                 if (p.layout == MMFE_LAYOUT_FEAT_MAJOR) {
                     float* o = p.out + ((int64_t)cur_row * p.n_mel + m) * p.out_frames + tf;
+#ifdef MMFE_ABL_NOSTORE      // diagnostic build: the stores stay in the code but never execute (no value is ever this bit pattern)
+                    if (__float_as_uint(v[4 * st]) != 0x7fc12345u) continue;
+#endif
                     if (p.vec_store && tf + 4 <= p.frames_valid) {
                         *reinterpret_cast<float4*>(o) = make_float4(v[4 * st], v[4 * st + 1], v[4 * st + 2], v[4 * st + 3]);
                     } else {
@@ -650,6 +758,14 @@ int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64
                      reinterpret_cast<uintptr_t>(src.base) % (pcm ? 8 : 16) == 0;
     int rc = MMFE_EINVAL;
     bool found = false;
+#if MMFE_R400_DIRECT
+#define MMFE_R400_SHAPE(IDX, A, B, C, D, SP)                                                                     \
+    if (plan.r400_shape == IDX) {                                                                                \
+        found = true;                                                                                            \
+        if (pcm) rc = launch_variant<int16_t, 0, false, A, B, C, D, SP>(a, octets, stream);                      \
+        else rc = launch_variant<float, 0, false, A, B, C, D, SP>(a, octets, stream);                            \
+    }
+#else
 #define MMFE_R400_SHAPE(IDX, A, B, C, D, SP)                                                                     \
     if (plan.r400_shape == IDX) {                                                                                \
         found = true;                                                                                            \
@@ -661,6 +777,7 @@ int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64
         else if (vec) rc = launch_variant<float, 0, true, A, B, C, D, SP>(a, octets, stream);                        \
         else rc = launch_variant<float, 0, false, A, B, C, D, SP>(a, octets, stream);                                \
     }
+#endif
     MMFE_R400_SHAPE(0, 5, 19, 17, 0, true)
     MMFE_R400_SHAPE(1, 8, 20, 20, 0, true)
     MMFE_R400_SHAPE(2, 4, 8, 12, 24, false)
