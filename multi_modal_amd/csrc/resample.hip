@@ -8,13 +8,27 @@
 // alignment and output count of scipy.signal.resample_poly (h centred on the output grid, ceil(n * up / down) outputs,
 // zeros outside the row).
 //
-// A block takes a tile of consecutive outputs of one row.  The input samples under the tile are staged once in LDS by
-// coalesced loads (16-bit PCM is decoded there), the polyphase bank sits in LDS as well (rows padded to whole 16-byte
-// groups, so a lane fetches four taps per read); each thread then walks its outputs.  HBM traffic is the algorithmic
-// minimum plus the J - 1 samples of history per tile.
+// Two kernels.
+//
+// resample_phase_kernel (ratios whose phase pattern lines up with the wave, e.g. 160/441, 1/3, 1/2): outputs m and m + up
+// use the same filter phase and sit exactly `down` input samples apart.  So the 64 lanes of a wave take outputs that are a
+// multiple L of `up` apart: every lane then needs the SAME tap weights, which makes them wave-uniform values that arrive
+// through the scalar cache and ride on the multiply-adds as scalar operands - no LDS or vector-memory traffic for the
+// filter at all.  A lane produces Q = 4 consecutive outputs; their input windows overlap, so it walks ONE window of
+// taps + (Q - 1) * down / up samples, reads each sample once from LDS (lane stride L * down / up: odd for 160/441, i.e.
+// conflict-free) and feeds it to the Q accumulators.  Per output that is (taps + 8) / 4 LDS reads instead of taps.  A block
+// stages the input of a tile of NB * 64 * L outputs in LDS (fetched one tile ahead into registers, 16-bit PCM decoded
+// there), collects the tile's outputs in a second LDS area (a lane's outputs are L floats apart) and stores them as whole
+// contiguous rows.
+//
+// resample_kernel (any other ratio): a block takes a tile of consecutive outputs of one row, input samples and the
+// polyphase bank in LDS (bank rows padded to whole 16-byte groups, four taps per read), one thread per output.
 #include "mmfe_internal.h"
+#include "fft_regs.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <string>
 #include <vector>
 
 namespace mmfe {
@@ -90,6 +104,118 @@ __global__ void __launch_bounds__(kThreads) resample_kernel(const ResampleArgs p
     }
 }
 
+
+// ---- wave-uniform-phase kernel --------------------------------------------------------------------------------------
+constexpr int kQ = 4;                    // consecutive outputs per lane
+constexpr int kMaxPhaseThreads = 1024;
+constexpr int kPhasePF = 36;             // prefetch registers per thread (samples of the next tile)
+constexpr int kPhaseLdsBytes = 158 * 1024;
+
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(4))) const f32x8 const_f32x8;     // read through the scalar cache
+typedef __attribute__((address_space(4))) const int const_int;
+
+struct ResamplePhaseArgs {
+    RowSource src;
+    float* out;
+    int n_rows;
+    int n_in;
+    int64_t n_out;             // outputs computed per row
+    int64_t out_stride;
+    int up, down;
+    int L;                     // outputs between neighbouring lanes (a multiple of up and of kQ)
+    int D;                     // input samples between neighbouring lanes: L * down / up
+    int nb;                    // lane blocks (64 lanes each) per tile
+    int groups;                // L / kQ: runs of kQ consecutive outputs inside L
+    int wlen;                  // window samples walked per run (a multiple of 8)
+    int tile_in;               // staged input samples per tile
+    int tile_out;              // nb * 64 * L
+    int ls;                    // floats between the output runs of neighbouring lanes in LDS (L, padded for conflict-free 16-byte writes)
+    int tiles_per_row;
+    const float* wt;           // [groups][wlen / 8][kQ][8]: weight of window sample s for output q of the run, zero outside its taps
+    const int* gi;             // [groups]: input offset of window sample 0 of the run
+};
+
+template <typename SMP>
+__global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const ResamplePhaseArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_x = reinterpret_cast<float*>(smem);                       // tile_in (rounded up to 4)
+    float* s_o = s_x + ((p.tile_in + 3) & ~3);                         // nb * 64 * ls
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_waves = blockDim.x >> 6;
+    const int64_t n_tiles = (int64_t)p.n_rows * p.tiles_per_row;
+    const int chunks = p.wlen >> 3;
+
+    SMP pf[kPhasePF];
+    // tile -> (row, first output); staged sample k of a tile is input sample lo + k of the row
+    auto fetch = [&](int64_t tile) {
+        if (tile >= n_tiles) return;
+        const int row = (int)(tile / p.tiles_per_row);
+        const int64_t m0 = (tile - (int64_t)row * p.tiles_per_row) * p.tile_out;
+        const int64_t lo = (m0 / p.up) * p.down - p.wlen;
+        const SMP* x = row_ptr_as<SMP>(p.src, row);
+        const int n_row = row_samples(p.src, row, p.n_in);
+#pragma unroll
+        for (int q = 0; q < kPhasePF; ++q) {
+            const int k = threadIdx.x + q * blockDim.x;
+            const int64_t g = lo + k;
+            pf[q] = (k < p.tile_in && g >= 0 && g < n_row) ? x[g] : SMP(0);
+        }
+    };
+    fetch(blockIdx.x);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int row = (int)(tile / p.tiles_per_row);
+        const int64_t m0 = (tile - (int64_t)row * p.tiles_per_row) * p.tile_out;
+        // ---- stage: registers -> LDS (the previous tile's readers passed the barrier that ended its drain) ----
+#pragma unroll
+        for (int q = 0; q < kPhasePF; ++q) {
+            const int k = threadIdx.x + q * blockDim.x;
+            if (k < p.tile_in) s_x[k] = sample_value(pf[q]);
+        }
+        lds_barrier();
+        fetch(tile + gridDim.x);                                        // in flight under the arithmetic below
+        // ---- runs: (lane block, group) pairs spread over the waves ----
+        for (int task = wave; task < p.nb * p.groups; task += n_waves) {
+            const int blk = task / p.groups;
+            const int u = task - blk * p.groups;
+            const float* xl = s_x + p.wlen + (blk * 64 + lane) * p.D + ((const_int*)p.gi)[u];
+            const_f32x8* w = ((const_f32x8*)p.wt) + (int64_t)u * chunks * kQ;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int c = 0; c < chunks; ++c) {
+                const f32x8 w0 = w[c * kQ], w1 = w[c * kQ + 1], w2 = w[c * kQ + 2], w3 = w[c * kQ + 3];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xv = xl[-(c * 8 + e)];
+                    a0 = fmaf(w0[e], xv, a0);
+                    a1 = fmaf(w1[e], xv, a1);
+                    a2 = fmaf(w2[e], xv, a2);
+                    a3 = fmaf(w3[e], xv, a3);
+                }
+            }
+            *reinterpret_cast<f32x4*>(s_o + (blk * 64 + lane) * p.ls + kQ * u) = f32x4{a0, a1, a2, a3};
+        }
+        lds_barrier();
+        // ---- drain: lane run j holds outputs m0 + j * L .. + L - 1 ----
+        float* orow = p.out + (int64_t)row * p.out_stride;
+        if (p.ls == p.L) {
+            for (int k = threadIdx.x; k < p.tile_out; k += blockDim.x) {
+                const int64_t m = m0 + k;
+                if (m < p.n_out) __builtin_nontemporal_store(s_o[k], orow + m);
+            }
+        } else {
+            for (int j = wave; j < p.nb * 64; j += n_waves) {
+                for (int k = lane; k < p.L; k += 64) {
+                    const int64_t m = m0 + (int64_t)j * p.L + k;
+                    if (m < p.n_out) __builtin_nontemporal_store(s_o[j * p.ls + k], orow + m);
+                }
+            }
+        }
+        // (no barrier here: the next step's stage only writes s_x, whose readers passed the barrier above, and s_o is not written
+        // again before the barrier that follows the stage)
+    }
+}
+
 }  // namespace
 
 int resample_prepare(Plan& plan) {
@@ -122,7 +248,59 @@ int resample_prepare(Plan& plan) {
         set_error("RESAMPLE: ratio %d/%d with %d taps per phase needs more than %d staged samples per tile", up, down, taps, kMaxTileIn);
         return MMFE_EINVAL;
     }
-    return upload(&plan.d_window, bank);
+    int rc = upload(&plan.d_window, bank);
+    if (rc) return rc;
+
+    // ---- wave-uniform-phase kernel: applicable when lanes L = up * ceil(kQ / up) outputs apart leave whole runs of kQ ----
+    plan.rs_L = 0;
+    const char* force = std::getenv("MMFE_RESAMPLE_FORM");          // tuning / test knob, read once per plan: "general" forces the general kernel
+    if (force != nullptr && std::string(force) == "general") return MMFE_OK;
+    const int64_t L = (int64_t)up * ((kQ + up - 1) / up);
+    if (L % kQ != 0 || L > 4096) return MMFE_OK;
+    const int64_t D = L * down / up;
+    const int groups = (int)(L / kQ);
+    const int pre = (half + pre_pad) / down;
+    std::vector<int32_t> gi(groups);
+    std::vector<int> io(groups * kQ), ph(groups * kQ);
+    int max_back = 0, i_max = 0;
+    for (int u = 0; u < groups; ++u) {
+        for (int q = 0; q < kQ; ++q) {
+            const int64_t t = (int64_t)(kQ * u + q + pre) * down;
+            io[u * kQ + q] = (int)(t / up);
+            ph[u * kQ + q] = (int)(t % up);
+        }
+        gi[u] = io[u * kQ + kQ - 1];
+        i_max = std::max(i_max, gi[u]);
+        max_back = std::max(max_back, gi[u] - io[u * kQ]);
+    }
+    const int wlen = (taps + max_back + 7) & ~7;
+    std::vector<float> wt((size_t)groups * wlen * kQ, 0.f);
+    for (int u = 0; u < groups; ++u)
+        for (int sidx = 0; sidx < wlen; ++sidx)
+            for (int q = 0; q < kQ; ++q) {
+                const int t = sidx - (gi[u] - io[u * kQ + q]);
+                if (t >= 0 && t < taps)
+                    wt[(((size_t)u * (wlen / 8) + sidx / 8) * kQ + q) * 8 + sidx % 8] = bank[(size_t)ph[u * kQ + q] * taps_padded + t];
+            }
+    // lane runs in the output area: a stride whose quarter is odd keeps the 16-byte writes of 64 lanes on distinct banks
+    const int ls = (L / 4) % 2 == 1 ? (int)L : (int)L + 4;
+    // lane blocks per tile: as many as LDS and the prefetch registers hold
+    int nb = 0, threads = 0, tile_in = 0;
+    for (int cand = 1; cand <= 64; ++cand) {
+        const int64_t t_in = wlen + (int64_t)cand * 64 * D + i_max + 1;
+        const int64_t bytes = 4 * (((t_in + 3) & ~(int64_t)3) + (int64_t)cand * 64 * ls);
+        const int tasks = cand * groups;
+        const int rounds = (tasks + 15) / 16;
+        const int nw = (tasks + rounds - 1) / rounds;
+        if (bytes > kPhaseLdsBytes || t_in > (int64_t)kPhasePF * 64 * nw) break;
+        nb = cand; threads = 64 * nw; tile_in = (int)t_in;
+    }
+    if (nb == 0) return MMFE_OK;
+    if ((rc = upload(&plan.d_tw_a, wt))) return rc;
+    if ((rc = upload(&plan.d_mel_start, gi))) return rc;
+    plan.rs_L = (int)L; plan.rs_D = (int)D; plan.rs_nb = nb; plan.rs_groups = groups; plan.rs_wlen = wlen;
+    plan.rs_tile_in = tile_in; plan.rs_ls = ls; plan.rs_threads = threads;
+    return MMFE_OK;
 }
 
 int64_t resample_out_len(const mmfe_spec& s, int64_t n) {
@@ -137,6 +315,34 @@ int resample_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
     if (n_rows <= 0 || n_out <= 0) return MMFE_OK;
     if (n_samples >= ((int64_t)1 << 31) / 2 || n_rows >= (int64_t)1 << 31) { set_error("RESAMPLE: row too long for one launch"); return MMFE_EINVAL; }
     const int up = s.n_fft, down = s.hop, n_taps = s.win_len;
+    const bool pcm = s.in_dtype == MMFE_IN_S16;
+    if (plan.rs_L > 0) {
+        ResamplePhaseArgs a{};
+        a.src = src;
+        a.out = out;
+        a.n_rows = (int)n_rows;
+        a.n_in = (int)n_samples;
+        a.n_out = n_out;
+        a.out_stride = out_len;
+        a.up = up; a.down = down;
+        a.L = plan.rs_L; a.D = plan.rs_D; a.nb = plan.rs_nb; a.groups = plan.rs_groups; a.wlen = plan.rs_wlen;
+        a.tile_in = plan.rs_tile_in; a.ls = plan.rs_ls;
+        a.tile_out = a.nb * 64 * a.L;
+        a.tiles_per_row = (int)((n_out + a.tile_out - 1) / a.tile_out);
+        a.wt = plan.d_tw_a;
+        a.gi = plan.d_mel_start;
+        const size_t lds = 4 * ((size_t)((a.tile_in + 3) & ~3) + (size_t)a.nb * 64 * a.ls);
+        const void* fn = pcm ? reinterpret_cast<const void*>(&resample_phase_kernel<int16_t>) : reinterpret_cast<const void*>(&resample_phase_kernel<float>);
+        int per_cu = 1, cus = 256;
+        const int rc = kernel_prepare(fn, plan.rs_threads, lds, &per_cu, &cus);
+        if (rc) return rc;
+        const int64_t n_tiles = n_rows * a.tiles_per_row;
+        const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)cus * std::max(1, per_cu));
+        if (pcm) hipLaunchKernelGGL(resample_phase_kernel<int16_t>, dim3(grid), dim3(plan.rs_threads), lds, stream, a);
+        else hipLaunchKernelGGL(resample_phase_kernel<float>, dim3(grid), dim3(plan.rs_threads), lds, stream, a);
+        MMFE_HIP_CHECK(hipGetLastError());
+        return MMFE_OK;
+    }
     const int half = (n_taps - 1) / 2;
     const int pre_pad = down - half % down;
     ResampleArgs a{};
@@ -162,7 +368,6 @@ int resample_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
     const size_t bank_bytes = (size_t)up * a.taps_padded * 4;
     const bool bank_lds = bank_bytes <= (size_t)kMaxBankBytes;
     const size_t lds = (bank_lds ? bank_bytes : 0) + (size_t)a.tile_in * 4;
-    const bool pcm = s.in_dtype == MMFE_IN_S16;
     const void* fn = pcm ? (bank_lds ? reinterpret_cast<const void*>(&resample_kernel<int16_t, true>) : reinterpret_cast<const void*>(&resample_kernel<int16_t, false>))
                          : (bank_lds ? reinterpret_cast<const void*>(&resample_kernel<float, true>) : reinterpret_cast<const void*>(&resample_kernel<float, false>));
     int per_cu = 1, cus = 256;

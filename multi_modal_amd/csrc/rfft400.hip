@@ -42,7 +42,7 @@ constexpr int kBins = 201;
 constexpr int kWaves = 4;                           // waves per block
 constexpr int kMaxHop = 160;
 constexpr int kMaxSpan = 7 * kMaxHop + kN;          // samples under one wave pass: 1520
-constexpr int kPF = (kMaxSpan / 4 + 63) / 64;       // prefetch registers (16-byte) per lane: 6
+[[maybe_unused]] constexpr int kPF = (kMaxSpan / 4 + 63) / 64;       // prefetch registers (16-byte) per lane: 6
 constexpr int kTileStride = 18;                     // complex numbers per transpose-tile row (16 + padding, keeps rows 16-byte aligned)
 constexpr int kPairBytes = 25 * kTileStride * 8 + 112;   // 3712: transpose tile / natural-order spectrum of one frame pair; = 32 dwords
                                                          // mod 64, so the two pairs of a 32-lane half sit on disjoint LDS banks
@@ -197,7 +197,9 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
     const int pr = lane >> 4;      // frame pair within the wave
     const int b = lane & 15;       // lane within the pair's group
     char* wave_area = smem + kTwBytes + wave * kWaveBytes;
+#if !MMFE_R400_DIRECT
     float* stage = reinterpret_cast<float*>(wave_area);
+#endif
     float2* tile = reinterpret_cast<float2*>(wave_area + pr * kPairBytes);
     float* parea = reinterpret_cast<float*>(wave_area);
 
@@ -207,7 +209,9 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
     wave_lds_fence();
 
     const int hop = HOP > 0 ? HOP : p.hop;
+#if !MMFE_R400_DIRECT
     const int span4 = (7 * hop + kN + 3) & ~3;      // samples staged per pass, rounded up to whole 16-byte pieces
+#endif
 
     // ---- per-lane constants, resident for the life of the kernel -----------------------------------
     float win[25];
@@ -754,7 +758,7 @@ int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64
         a.rowmin = a.rowmax + cs.capacity;
     }
     const bool pcm = s.in_dtype == MMFE_IN_S16;
-    const bool vec = s.hop % 4 == 0 && a.shift % 4 == 0 && src.offsets == nullptr && src.stride % 4 == 0 &&
+    [[maybe_unused]] const bool vec = s.hop % 4 == 0 && a.shift % 4 == 0 && src.offsets == nullptr && src.stride % 4 == 0 &&
                      reinterpret_cast<uintptr_t>(src.base) % (pcm ? 8 : 16) == 0;
     int rc = MMFE_EINVAL;
     bool found = false;

@@ -55,6 +55,38 @@ class RunningNorm:
         return mean, var ** 0.5
 
 
+class BatchAveragedNorm:
+    """The statistics pass at the bottom of classification/recognition/dataset/epic_kitchen.py (lines 275-290): per DataLoader
+    batch the mean and the UNBIASED variance (`tensor.std() ** 2`) of the spectrogram batch, both averaged over the batches;
+    the reported std is the square root of the averaged variance.  That differs from RunningNorm, which pools all values
+    (population variance about the global mean): batch-to-batch drift of the mean is not part of this figure.
+    Sums are reduced on the GPU in float64 (one kernel per batch, no host synchronisation until finalize)."""
+
+    def __init__(self, device: torch.device = None):
+        require_gpu()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.acc = torch.zeros(3, dtype=torch.float64, device=self.device)      # sum of batch means, sum of batch variances, batches
+
+    def update(self, batch: torch.Tensor) -> None:
+        n = batch.numel()
+        if n < 2:
+            raise ValueError("a batch needs at least two values for an unbiased variance")
+        r = RunningNorm(self.device)
+        r.update(batch)
+        s, q = r.sums[0], r.sums[1]
+        self.acc += torch.stack([s / n, (q - s * s / n) / (n - 1), torch.ones((), dtype=torch.float64, device=self.device)])
+
+    def finalize(self, group=None) -> Tuple[float, float]:
+        """(mean of the batch means, sqrt of the mean of the batch variances); with several ranks every rank's batches count."""
+        acc = self.acc.clone()
+        if dist.is_initialized():
+            dist.all_reduce(acc, group=group)
+        m, v, k = acc.tolist()
+        if k == 0:
+            return float("nan"), float("nan")
+        return m / k, max(v / k, 0.0) ** 0.5
+
+
 def cal_norm(features: torch.Tensor) -> Tuple[float, float]:
     """Mean and standard deviation of one feature tensor."""
     r = RunningNorm(features.device if features.is_cuda else None)

@@ -582,6 +582,23 @@ def test_cal_norm(mm):
     assert abs(std - f.double().std(unbiased=False).item()) < 1e-6
 
 
+def test_epic_batch_averaged_statistics(mm):
+    """The EPIC statistics pass (epic_kitchen.py:275-290): mean of per-batch means, sqrt of the mean of per-batch UNBIASED variances,
+    against the same formula in torch float64; the pooled RunningNorm figure differs when the batch means drift."""
+    g = torch.Generator(device="cuda").manual_seed(8)
+    batches = [torch.randn(48, 1, 64, 64, device="cuda", generator=g) * (1.0 + 0.1 * i) + 0.5 * i for i in range(5)]
+    norm = mm.stats.BatchAveragedNorm()
+    pooled = mm.stats.RunningNorm()
+    for bt in batches:
+        norm.update(bt)
+        pooled.update(bt)
+    mean, std = norm.finalize()
+    ref_mean = sum(bt.double().mean().item() for bt in batches) / len(batches)
+    ref_std = (sum(bt.double().std().item() ** 2 for bt in batches) / len(batches)) ** 0.5
+    assert abs(mean - ref_mean) <= 1e-9 and abs(std - ref_std) <= 1e-9
+    assert pooled.finalize()[1] > std + 0.1          # pooled variance also holds the drift of the batch means
+
+
 def test_full_size_properties(mm):
     """The headline benchmark configuration at full size (4096 VGGSound clips): properties that do not need the oracle.
     Every clip is one of 8 distinct waveforms, so equal clips must give bit-identical features wherever
