@@ -132,6 +132,7 @@ struct ResamplePhaseArgs {
     int tile_out;              // nb * 64 * L
     int ls;                    // floats between the output runs of neighbouring lanes in LDS (L, padded for conflict-free 16-byte writes)
     int tiles_per_row;
+    int vec_out;               // output rows start 16-byte aligned: whole tiles are stored 16 bytes per lane
     const float* wt;           // [groups][wlen / 8][kQ][8]: weight of window sample s for output q of the run, zero outside its taps
     const int* gi;             // [groups]: input offset of window sample 0 of the run
 };
@@ -144,34 +145,45 @@ __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_waves = blockDim.x >> 6;
-    const int64_t n_tiles = (int64_t)p.n_rows * p.tiles_per_row;
+    const unsigned n_tiles = (unsigned)p.n_rows * (unsigned)p.tiles_per_row;      // < 2^31 (checked by the launcher)
     const int chunks = p.wlen >> 3;
 
     SMP pf[kPhasePF];
     // tile -> (row, first output); staged sample k of a tile is input sample lo + k of the row
-    auto fetch = [&](int64_t tile) {
+    auto fetch = [&](unsigned tile) {
         if (tile >= n_tiles) return;
-        const int row = (int)(tile / p.tiles_per_row);
-        const int64_t m0 = (tile - (int64_t)row * p.tiles_per_row) * p.tile_out;
-        const int64_t lo = (m0 / p.up) * p.down - p.wlen;
+        const unsigned row = tile / (unsigned)p.tiles_per_row;
+        const int m0 = (int)(tile - row * (unsigned)p.tiles_per_row) * p.tile_out;      // < n_out + tile_out < 2^31 (checked by the launcher)
+        const int lo = (m0 / p.up) * p.down - p.wlen;
         const SMP* x = row_ptr_as<SMP>(p.src, row);
         const int n_row = row_samples(p.src, row, p.n_in);
+        if (n_row <= 0) {            // block-uniform
+#pragma unroll
+            for (int q = 0; q < kPhasePF; ++q) pf[q] = SMP(0);      // (staged as zeros whatever they hold: every index is outside the row)
+            return;
+        }
+        // every load reads inside the row (index clamped); samples outside the row are zeroed when the registers are staged, so
+        // that nothing here waits for the loads
 #pragma unroll
         for (int q = 0; q < kPhasePF; ++q) {
-            const int k = threadIdx.x + q * blockDim.x;
-            const int64_t g = lo + k;
-            pf[q] = (k < p.tile_in && g >= 0 && g < n_row) ? x[g] : SMP(0);
+            const int g = lo + (int)threadIdx.x + q * (int)blockDim.x;
+            pf[q] = x[g < 0 ? 0 : (g < n_row ? g : n_row - 1)];
         }
     };
     fetch(blockIdx.x);
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int row = (int)(tile / p.tiles_per_row);
-        const int64_t m0 = (tile - (int64_t)row * p.tiles_per_row) * p.tile_out;
+    for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const unsigned row = tile / (unsigned)p.tiles_per_row;
+        const int m0 = (int)(tile - row * (unsigned)p.tiles_per_row) * p.tile_out;
         // ---- stage: registers -> LDS (the previous tile's readers passed the barrier that ended its drain) ----
+        {
+            const int lo = (m0 / p.up) * p.down - p.wlen;
+            const int n_row = row_samples(p.src, row, p.n_in);
 #pragma unroll
-        for (int q = 0; q < kPhasePF; ++q) {
-            const int k = threadIdx.x + q * blockDim.x;
-            if (k < p.tile_in) s_x[k] = sample_value(pf[q]);
+            for (int q = 0; q < kPhasePF; ++q) {
+                const int k = threadIdx.x + q * blockDim.x;
+                const int g = lo + k;
+                if (k < p.tile_in) s_x[k] = (g >= 0 && g < n_row) ? sample_value(pf[q]) : 0.f;
+            }
         }
         lds_barrier();
         fetch(tile + gridDim.x);                                        // in flight under the arithmetic below
@@ -182,6 +194,9 @@ __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const 
             const float* xl = s_x + p.wlen + (blk * 64 + lane) * p.D + ((const_int*)p.gi)[u];
             const_f32x8* w = ((const_f32x8*)p.wt) + (int64_t)u * chunks * kQ;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            // (requesting the next chunk's weights and samples ahead of the multiply-adds, in a second register set, measured the
+            // same: scalar loads and LDS reads share one counter and scalar loads return out of order, so any wait is a wait for
+            // everything, and the other waves of the SIMD already fill the gaps)
             for (int c = 0; c < chunks; ++c) {
                 const f32x8 w0 = w[c * kQ], w1 = w[c * kQ + 1], w2 = w[c * kQ + 2], w3 = w[c * kQ + 3];
 #pragma unroll
@@ -202,6 +217,13 @@ __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const 
             for (int k = threadIdx.x; k < p.tile_out; k += blockDim.x) {
                 const int64_t m = m0 + k;
                 if (m < p.n_out) __builtin_nontemporal_store(s_o[k], orow + m);
+            }
+        } else if (p.vec_out && m0 + p.tile_out <= p.n_out) {
+            // a lane run is L contiguous floats in LDS and in memory, both 16-byte aligned
+            const int l4 = p.L >> 2;
+            for (int j = wave; j < p.nb * 64; j += n_waves) {
+                for (int k = lane; k < l4; k += 64)
+                    __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(s_o + j * p.ls + 4 * k), reinterpret_cast<f32x4*>(orow + m0 + (int64_t)j * p.L) + k);
             }
         } else {
             for (int j = wave; j < p.nb * 64; j += n_waves) {
@@ -331,12 +353,14 @@ int resample_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
         a.tiles_per_row = (int)((n_out + a.tile_out - 1) / a.tile_out);
         a.wt = plan.d_tw_a;
         a.gi = plan.d_mel_start;
+        a.vec_out = (reinterpret_cast<uintptr_t>(out) % 16 == 0 && out_len % 4 == 0) ? 1 : 0;
         const size_t lds = 4 * ((size_t)((a.tile_in + 3) & ~3) + (size_t)a.nb * 64 * a.ls);
         const void* fn = pcm ? reinterpret_cast<const void*>(&resample_phase_kernel<int16_t>) : reinterpret_cast<const void*>(&resample_phase_kernel<float>);
         int per_cu = 1, cus = 256;
         const int rc = kernel_prepare(fn, plan.rs_threads, lds, &per_cu, &cus);
         if (rc) return rc;
         const int64_t n_tiles = n_rows * a.tiles_per_row;
+        if (n_tiles >= ((int64_t)1 << 31) - 65536 || n_out + a.tile_out >= (int64_t)1 << 31) { set_error("RESAMPLE: batch too large for one launch"); return MMFE_EINVAL; }
         const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)cus * std::max(1, per_cu));
         if (pcm) hipLaunchKernelGGL(resample_phase_kernel<int16_t>, dim3(grid), dim3(plan.rs_threads), lds, stream, a);
         else hipLaunchKernelGGL(resample_phase_kernel<float>, dim3(grid), dim3(plan.rs_threads), lds, stream, a);

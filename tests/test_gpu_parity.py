@@ -1166,3 +1166,20 @@ def test_resample_rejects_bad_plans(mm):
     plan = N.Plan(N.make_spec(kind=N.KIND_RESAMPLE, n_fft=160, hop=441, win_len=len(taps)), taps, device=0)
     assert plan.kernel == "resample"
     plan.close()
+
+
+def test_resample_both_kernels_agree(mm, O, monkeypatch):
+    """44.1 -> 16 kHz runs on the wave-uniform-phase kernel; MMFE_RESAMPLE_FORM=general (read at plan creation) forces the general
+    kernel, which otherwise only serves ratios such as 441/160.  Same filter, same alignment: both within 2e-6 of scipy and within
+    1e-6 of each other (the accumulation order differs)."""
+    x = np.stack([synth("noise0.1", 50001, 4242), synth("uniform", 50001, 4243)])
+    ref = O.resample_poly(x, 44100, 16000)
+    mm.plans.clear_plans()
+    fast = mm.resample_batch(torch.from_numpy(x).cuda(), 44100, 16000).cpu().numpy()
+    mm.plans.clear_plans()
+    monkeypatch.setenv("MMFE_RESAMPLE_FORM", "general")
+    slow = mm.resample_batch(torch.from_numpy(x).cuda(), 44100, 16000).cpu().numpy()
+    monkeypatch.delenv("MMFE_RESAMPLE_FORM")
+    mm.plans.clear_plans()
+    assert np.abs(fast - ref).max() <= 2e-6 and np.abs(slow - ref).max() <= 2e-6
+    assert np.abs(fast - slow).max() <= 1e-6
