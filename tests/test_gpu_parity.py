@@ -1183,3 +1183,29 @@ def test_resample_both_kernels_agree(mm, O, monkeypatch):
     mm.plans.clear_plans()
     assert np.abs(fast - ref).max() <= 2e-6 and np.abs(slow - ref).max() <= 2e-6
     assert np.abs(fast - slow).max() <= 1e-6
+
+
+def test_device_prefetcher_overlapped_batches(mm, O):
+    """DataLoader-shaped batches (waveforms + labels) through the pinned-buffer prefetcher with the fused transform: every batch
+    equals the direct call on the same clips, in order, for several depths, batch counts around the pipeline depth, a ragged last
+    batch, int16 PCM clips, and dict batches; tensors already on the device pass through."""
+    from multi_modal_amd.loader import DevicePrefetcher
+    rng = np.random.default_rng(5)
+    clips = [torch.from_numpy((0.1 * rng.standard_normal((3 if i == 6 else 4, 1, 16000))).astype(np.float32)) for i in range(7)]
+    labels = [torch.arange(c.shape[0]) + 10 * i for i, c in enumerate(clips)]
+    want = [mm.preprocessing_audio_batch(c.cuda()) for c in clips]
+    for depth in (2, 3, 4):
+        for n_batches in (0, 1, 2, 3, 7):
+            got = list(DevicePrefetcher(zip(clips[:n_batches], labels[:n_batches]), depth=depth,
+                                        transform=lambda b: (mm.preprocessing_audio_batch(b[0]), b[1])))
+            assert len(got) == n_batches
+            for (f, l), w, lab in zip(got, want, labels):
+                assert f.is_cuda and l.is_cuda and torch.equal(f, w) and torch.equal(l.cpu(), lab)
+    pcm = [(c * 32767.0).round().to(torch.int16) for c in clips[:3]]
+    got = list(DevicePrefetcher(({"audio": p, "name": "clip%d" % i, "on_device": labels[i].cuda()} for i, p in enumerate(pcm)),
+                                transform=lambda b: {**b, "audio": mm.preprocessing_audio_batch(b["audio"])}))
+    for i, g in enumerate(got):
+        assert g["name"] == "clip%d" % i and torch.equal(g["on_device"].cpu(), labels[i])
+        assert torch.equal(g["audio"], mm.preprocessing_audio_batch(pcm[i].cuda()))
+    with pytest.raises(ValueError):
+        DevicePrefetcher([], depth=1)
