@@ -572,16 +572,14 @@ constexpr MelShape kShapes[] = {
 };
 
 template <typename SMP, int HOP, bool VEC, int S0, int S1, int S2, int S3, bool SPLIT>
-int launch_variant(const Rfft400Args& a, int64_t octets, hipStream_t stream) {
+int launch_variant(const Rfft400Args& a, int64_t octets, int max_blocks_per_cu /* tuning, 0 = no limit */, int* cus_out, hipStream_t stream) {
     const void* fn = reinterpret_cast<const void*>(&rfft400_kernel<SMP, HOP, VEC, S0, S1, S2, S3, SPLIT>);
     const size_t lds = kTwBytes + (size_t)kWaves * kWaveBytes;
     int blocks_per_cu = 1, cus = 256;
     int rc = kernel_prepare(fn, 64 * kWaves, lds, &blocks_per_cu, &cus);
     if (rc) return rc;
-    if (const char* e = std::getenv("MMFE_R400_BLOCKS_PER_CU")) {     // tuning: fewer resident blocks (the grid is persistent)
-        const int v = std::atoi(e);
-        if (v >= 1 && v < blocks_per_cu) blocks_per_cu = v;
-    }
+    if (max_blocks_per_cu >= 1 && max_blocks_per_cu < blocks_per_cu) blocks_per_cu = max_blocks_per_cu;
+    *cus_out = cus;
     const int64_t want = (octets + kWaves - 1) / kWaves;
     const int grid = (int)std::min<int64_t>(want, (int64_t)cus * std::max(1, blocks_per_cu));
 #ifdef MMFE_STAMPS
@@ -717,6 +715,7 @@ int rfft400_prepare(Plan& plan) {
     if ((rc = upload(&plan.d_mel4_kstart, poff))) return rc;
     if ((rc = upload(&plan.d_r400_dst, dst))) return rc;
     if ((rc = upload(&plan.d_mel4_w, w))) return rc;
+    if (const char* e = std::getenv("MMFE_R400_BLOCKS_PER_CU")) plan.tune_blocks_per_cu = std::atoi(e);     // tuning knob, read once per plan
     return MMFE_OK;
 }
 
@@ -751,6 +750,7 @@ int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64
     a.mel_poff = plan.d_mel4_kstart;
     a.mel_dst = plan.d_r400_dst;
     a.mel_w = plan.d_mel4_w;
+    int cus = 256;
     if (clamp) {
         int rc = rowmax_init_launch(cs, n_rows, stream);
         if (rc) return rc;
@@ -766,20 +766,20 @@ int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64
 #define MMFE_R400_SHAPE(IDX, A, B, C, D, SP)                                                                     \
     if (plan.r400_shape == IDX) {                                                                                \
         found = true;                                                                                            \
-        if (pcm) rc = launch_variant<int16_t, 0, false, A, B, C, D, SP>(a, octets, stream);                      \
-        else rc = launch_variant<float, 0, false, A, B, C, D, SP>(a, octets, stream);                            \
+        if (pcm) rc = launch_variant<int16_t, 0, false, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream);                      \
+        else rc = launch_variant<float, 0, false, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream);                            \
     }
 #else
 #define MMFE_R400_SHAPE(IDX, A, B, C, D, SP)                                                                     \
     if (plan.r400_shape == IDX) {                                                                                \
         found = true;                                                                                            \
         if (pcm) {                                                                                               \
-            if (s.hop == 160 && vec) rc = launch_variant<int16_t, 160, true, A, B, C, D, SP>(a, octets, stream);     \
-            else if (vec) rc = launch_variant<int16_t, 0, true, A, B, C, D, SP>(a, octets, stream);                  \
-            else rc = launch_variant<int16_t, 0, false, A, B, C, D, SP>(a, octets, stream);                          \
-        } else if (s.hop == 160 && vec) rc = launch_variant<float, 160, true, A, B, C, D, SP>(a, octets, stream);    \
-        else if (vec) rc = launch_variant<float, 0, true, A, B, C, D, SP>(a, octets, stream);                        \
-        else rc = launch_variant<float, 0, false, A, B, C, D, SP>(a, octets, stream);                                \
+            if (s.hop == 160 && vec) rc = launch_variant<int16_t, 160, true, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream);     \
+            else if (vec) rc = launch_variant<int16_t, 0, true, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream);                  \
+            else rc = launch_variant<int16_t, 0, false, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream);                          \
+        } else if (s.hop == 160 && vec) rc = launch_variant<float, 160, true, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream);    \
+        else if (vec) rc = launch_variant<float, 0, true, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream);                        \
+        else rc = launch_variant<float, 0, false, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream);                                \
     }
 #endif
     MMFE_R400_SHAPE(0, 5, 19, 17, 0, true)
@@ -791,9 +791,6 @@ int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64
     if (!found) { set_error("rfft400: plan has no kernel variant"); return MMFE_EINVAL; }
     if (rc) return rc;
     if (clamp) {
-        int dev = 0, cus = 256;
-        MMFE_HIP_CHECK(hipGetDevice(&dev));
-        MMFE_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         const int64_t per_row = out_frames * (int64_t)s.n_mel;
         const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(64, per_row / 4096));
         const int grid = (int)std::min<int64_t>(n_rows * chunks, (int64_t)cus * 8);

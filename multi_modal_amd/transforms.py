@@ -5,8 +5,10 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+import hashlib
+
 from . import _native as N
-from .plans import run_rows, to_device_rows
+from .plans import cached_plan, run_rows, to_device_rows
 
 
 def frame_signal(signal: torch.Tensor, frame_length: int, hop_length: int, window: torch.Tensor = None) -> torch.Tensor:
@@ -21,12 +23,15 @@ def frame_signal(signal: torch.Tensor, frame_length: int, hop_length: int, windo
     if rows.dtype == torch.int16:
         rows = rows.to(torch.float32)      # framing moves values, it does not decode them: exact in float32
     x, origin = to_device_rows(rows)
-    spec = N.make_spec(kind=N.KIND_FRAME, win_len=int(frame_length), hop=int(hop_length), frames_mode=N.FRAMES_CEIL)
-    plan = N.Plan(spec, window.detach().to("cpu", torch.float32).numpy(), device=x.device.index)   # window is data: no cache
-    try:
-        y = run_rows(plan, x)
-        torch.cuda.current_stream(x.device).synchronize()   # the plan (and its window table) dies with this call
-    finally:
-        plan.close()
+    # the window is data: plans are cached by its bytes, so repeated calls with the same window neither rebuild the device
+    # table nor synchronise the stream
+    win = np.ascontiguousarray(window.detach().to("cpu", torch.float32).numpy())
+    key = ("frame", int(frame_length), int(hop_length), hashlib.sha1(win.tobytes()).hexdigest())
+
+    def build(dev: int) -> N.Plan:
+        spec = N.make_spec(kind=N.KIND_FRAME, win_len=int(frame_length), hop=int(hop_length), frames_mode=N.FRAMES_CEIL)
+        return N.Plan(spec, win, device=dev)
+
+    y = run_rows(cached_plan(key, x.device.index, build), x)
     y = y.reshape(*lead, y.shape[-2], y.shape[-1]).to(signal.dtype)
     return y if origin.type == "cuda" else y.to(origin)

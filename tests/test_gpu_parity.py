@@ -1209,3 +1209,33 @@ def test_device_prefetcher_overlapped_batches(mm, O):
         assert torch.equal(g["audio"], mm.preprocessing_audio_batch(pcm[i].cuda()))
     with pytest.raises(ValueError):
         DevicePrefetcher([], depth=1)
+
+
+def test_clamp_plan_refuses_more_rows_than_its_scratch_holds(mm):
+    """A clamp_below_max plan keeps per-row extremes for at most 2^20 rows per call: one row more is refused with a clear error
+    before anything is launched (the output keeps its fill), and the same plan still serves a smaller batch afterwards."""
+    rows = (1 << 20) + 1
+    x = torch.zeros(rows, 160, device="cuda")
+    out = torch.full((rows, 80, 1), 7.0, device="cuda")
+    with pytest.raises(mm.MmfeError, match="rows"):
+        mm.logmel.log_mel_spectrogram(x, out=out)
+    torch.cuda.synchronize()
+    assert torch.all(out == 7.0)
+    ok = mm.logmel.log_mel_spectrogram(x[:5])
+    assert ok.shape == (5, 80, 1) and torch.isfinite(ok).all()
+
+
+def test_frame_signal_plans_are_cached_by_window(mm, O):
+    """Repeated frame_signal calls with equal windows share one plan (no table rebuild, no stream synchronisation); another
+    window gets another plan and its own values."""
+    from multi_modal_amd import plans
+    x = torch.from_numpy(synth("noise0.1", 4000, 31)).cuda()
+    w1 = torch.hann_window(64)
+    w2 = torch.hamming_window(64)
+    a = mm.frame_signal(x, 64, 16, w1.cuda())
+    n_plans = len(plans._plans)
+    b = mm.frame_signal(x, 64, 16, w1.clone().cuda())
+    assert len(plans._plans) == n_plans and torch.equal(a, b)
+    c = mm.frame_signal(x, 64, 16, w2.cuda())
+    assert len(plans._plans) == n_plans + 1
+    assert torch.equal(a.cpu(), O.frame_signal(x.cpu(), 64, 16, w1)) and torch.equal(c.cpu(), O.frame_signal(x.cpu(), 64, 16, w2))
