@@ -62,6 +62,15 @@ constexpr int kStreams = 4;
                                 //    in LDS for the partners Z[400 - k].  0: all of Z is parked in natural order and both members are read back
 #endif
 
+#ifndef MMFE_R400_TWGROUP
+#define MMFE_R400_TWGROUP 8
+#endif
+#ifndef MMFE_R400_RANGES
+#define MMFE_R400_RANGES 1      // 1: a block works through one contiguous range of octets, so a wave stays inside a row for many passes and the
+                                //    per-row extremes of clamp_below_max are reduced across the wave once per row instead of once per pass.
+                                //    0: blocks take octets round-robin over the whole batch
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Rfft400Args {
@@ -230,9 +239,19 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
     // ---- work distribution: octet = 8 consecutive frames of one row; a block takes kWaves consecutive
     //      octets per round, so its waves stream one contiguous region and fill whole output lines ------
     const unsigned opr = (unsigned)(p.frames_valid + 7) >> 3;      // octets per row
+#if MMFE_R400_RANGES
+    // rounds of kWaves consecutive octets; block b owns rounds [b * per_block, (b + 1) * per_block)
+    const unsigned n_rounds = ((unsigned)p.n_rows * opr + kWaves - 1) / kWaves;
+    const unsigned per_block = (n_rounds + gridDim.x - 1) / gridDim.x;
+    const unsigned round0 = blockIdx.x * per_block;
+    unsigned rounds_left = round0 < n_rounds ? (n_rounds - round0 < per_block ? n_rounds - round0 : per_block) : 0;
+    const unsigned ostride = kWaves;
+    const unsigned oct0 = round0 * kWaves + wave;
+#else
     const unsigned ostride = gridDim.x * kWaves;
-    const unsigned d_row = ostride / opr, d_o = ostride - d_row * opr;
     const unsigned oct0 = blockIdx.x * kWaves + wave;
+#endif
+    const unsigned d_row = ostride / opr, d_o = ostride - d_row * opr;
     unsigned row = oct0 / opr, oq = oct0 - row * opr;               // wave-uniform
     auto advance = [&](unsigned& r, unsigned& o) {
         r += d_row;
@@ -304,7 +323,25 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
 #ifdef MMFE_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
 #endif
+    // feature-major 16-byte stores: the lane's part of the address that does not change from pass to pass
+    int coff[kStreams];
+#pragma unroll
+    for (int st = 0; st < kStreams; ++st) coff[st] = dst[st] >= 0 ? (dst[st] & 0xffff) * p.out_frames + 4 * (dst[st] >> 16) : 0;
+    float lmax = -INFINITY, lmin = INFINITY;      // running extremes of the row the wave is in (clamp_below_max plans)
+    auto flush_extremes = [&](unsigned r) {
+        const float wmax = wave_max(lmax), wmin = wave_min(lmin);
+        if (lane == 0 && wmax > -INFINITY) {
+            atomicMax(p.rowmax + r, float_to_ordered(wmax));
+            atomicMin(p.rowmin + r, float_to_ordered(wmin));
+        }
+        lmax = -INFINITY;
+        lmin = INFINITY;
+    };
+#if MMFE_R400_RANGES
+    for (; rounds_left > 0 && row < (unsigned)p.n_rows; --rounds_left) {
+#else
     while (row < (unsigned)p.n_rows) {
+#endif
         MMFE_STAMP(0);
         const int t0 = (int)oq * 8;          // first frame of the octet
         const unsigned cur_row = row;
@@ -342,25 +379,26 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
         fft25(z);
         // The twiddle table and the tile are both LDS, and the compiler cannot tell them apart: a twiddle read
         // placed after a tile write stays behind it and then costs a full LDS round trip before its product can be
-        // written.  So the reads run one group of 8 ahead of the writes: three round trips instead of 24.
+        // written.  So the reads run one group of MMFE_R400_TWGROUP ahead of the writes: 24 / group round trips instead of 24.
         {
-            float2 tw_cur[8], tw_nxt[8];
+            constexpr int G = MMFE_R400_TWGROUP;      // twiddles fetched per LDS round trip (24 = 3 x 8 = 6 x 4)
+            float2 tw_cur[G], tw_nxt[G];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) tw_cur[j] = s_tw[(1 + j) * 16 + b];
+            for (int j = 0; j < G; ++j) tw_cur[j] = s_tw[(1 + j) * 16 + b];
             tile[b] = z[fft25_pos(0)];
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                if (g < 2) {
+            for (int g = 0; g < 24 / G; ++g) {
+                if (g + 1 < 24 / G) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) tw_nxt[j] = s_tw[(9 + 8 * g + j) * 16 + b];
+                    for (int j = 0; j < G; ++j) tw_nxt[j] = s_tw[(1 + G * (g + 1) + j) * 16 + b];
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int c = 1 + 8 * g + j;
+                for (int j = 0; j < G; ++j) {
+                    const int c = 1 + G * g + j;
                     tile[c * kTileStride + b] = cmul(z[fft25_pos(c)], tw_cur[j]);
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) tw_cur[j] = tw_nxt[j];
+                for (int j = 0; j < G; ++j) tw_cur[j] = tw_nxt[j];
             }
         }
         wave_lds_fence();
@@ -484,55 +522,70 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
         }
         MMFE_STAMP(6);
         apply_log_affine_block(v, p.la);
-        float lmax = -INFINITY, lmin = INFINITY;
+        if (p.layout == MMFE_LAYOUT_FEAT_MAJOR && p.vec_store && t0 + 8 <= p.frames_valid) {
+            // whole octet, 16-byte feature-major stores (the regular case): no per-frame predicates, one 64-bit scalar base per pass
+            float* obase = p.out + ((int64_t)cur_row * p.n_mel * p.out_frames + t0);
 #pragma unroll
-        for (int st = 0; st < kStreams; ++st) {
-            if (kSteps[st] == 0) continue;
-            // lane = 4*blk + j holds filter j of the block's unit for its 4 frames in v[4*st .. 4*st+3]
-            const int d = dst[st];
-            const int m = d & 0xffff;
-            const int tf = t0 + 4 * (d >> 16);          // first of the lane's 4 frames
-            if (d >= 0) {
-                if (p.rowmax != nullptr) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        lmax = tf + i < p.frames_valid ? fmaxf(lmax, v[4 * st + i]) : lmax;
-                        lmin = tf + i < p.frames_valid ? fminf(lmin, v[4 * st + i]) : lmin;
+            for (int st = 0; st < kStreams; ++st) {
+                if (kSteps[st] == 0) continue;
+                if (dst[st] >= 0) {
+                    if (p.rowmax != nullptr) {
+                        lmax = fmaxf(fmaxf(lmax, v[4 * st]), fmaxf(v[4 * st + 1], fmaxf(v[4 * st + 2], v[4 * st + 3])));
+                        lmin = fminf(fminf(lmin, v[4 * st]), fminf(v[4 * st + 1], fminf(v[4 * st + 2], v[4 * st + 3])));
                     }
-                }
-                if (p.layout == MMFE_LAYOUT_FEAT_MAJOR) {
-                    float* o = p.out + ((int64_t)cur_row * p.n_mel + m) * p.out_frames + tf;
 #ifdef MMFE_ABL_NOSTORE      // diagnostic build: the stores stay in the code but never execute (no value is ever this bit pattern)
                     if (__float_as_uint(v[4 * st]) != 0x7fc12345u) continue;
 #endif
-                    if (p.vec_store && tf + 4 <= p.frames_valid) {
-                        *reinterpret_cast<float4*>(o) = make_float4(v[4 * st], v[4 * st + 1], v[4 * st + 2], v[4 * st + 3]);
+                    *reinterpret_cast<float4*>(obase + coff[st]) = make_float4(v[4 * st], v[4 * st + 1], v[4 * st + 2], v[4 * st + 3]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int st = 0; st < kStreams; ++st) {
+                if (kSteps[st] == 0) continue;
+                // lane = 4*blk + j holds filter j of the block's unit for its 4 frames in v[4*st .. 4*st+3]
+                const int d = dst[st];
+                const int m = d & 0xffff;
+                const int tf = t0 + 4 * (d >> 16);          // first of the lane's 4 frames
+                if (d >= 0) {
+                    if (p.rowmax != nullptr) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            lmax = tf + i < p.frames_valid ? fmaxf(lmax, v[4 * st + i]) : lmax;
+                            lmin = tf + i < p.frames_valid ? fminf(lmin, v[4 * st + i]) : lmin;
+                        }
+                    }
+                    if (p.layout == MMFE_LAYOUT_FEAT_MAJOR) {
+                        float* o = p.out + ((int64_t)cur_row * p.n_mel + m) * p.out_frames + tf;
+#ifdef MMFE_ABL_NOSTORE      // diagnostic build: the stores stay in the code but never execute (no value is ever this bit pattern)
+                        if (__float_as_uint(v[4 * st]) != 0x7fc12345u) continue;
+#endif
+                        if (p.vec_store && tf + 4 <= p.frames_valid) {
+                            *reinterpret_cast<float4*>(o) = make_float4(v[4 * st], v[4 * st + 1], v[4 * st + 2], v[4 * st + 3]);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (tf + i < p.frames_valid) o[i] = v[4 * st + i];
+                        }
                     } else {
+                        float* o = p.out + ((int64_t)cur_row * p.out_frames + tf) * p.n_mel + m;
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            if (tf + i < p.frames_valid) o[i] = v[4 * st + i];
+                            if (tf + i < p.frames_valid) o[(int64_t)i * p.n_mel] = v[4 * st + i];
                     }
-                } else {
-                    float* o = p.out + ((int64_t)cur_row * p.out_frames + tf) * p.n_mel + m;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (tf + i < p.frames_valid) o[(int64_t)i * p.n_mel] = v[4 * st + i];
                 }
             }
         }
-        if (p.rowmax != nullptr) {
-            lmax = wave_max(lmax);
-            lmin = wave_min(lmin);
-            if (lane == 0 && lmax > -INFINITY) {
-                atomicMax(p.rowmax + cur_row, float_to_ordered(lmax));
-                atomicMin(p.rowmin + cur_row, float_to_ordered(lmin));
-            }
-        }
+        // the extremes go to memory when the wave leaves the row (with contiguous block ranges: once per row, not once per pass)
+        if (p.rowmax != nullptr && (row != cur_row || MMFE_R400_RANGES == 0)) flush_extremes(cur_row);
         MMFE_STAMP(7);
 #ifdef MMFE_STAMPS
         st_acc[7] += 1;
 #endif
         wave_lds_fence();
+#if MMFE_R400_RANGES
+        if (p.rowmax != nullptr && row == cur_row && rounds_left == 1) flush_extremes(cur_row);     // the range ends inside this row
+#endif
     }
 #ifdef MMFE_STAMPS
     if (lane == 0)
@@ -743,7 +796,7 @@ int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64
     a.pad_mode = s.pad_mode;
     a.n_mel = s.n_mel;
     a.layout = s.layout;
-    a.vec_store = (out_frames % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 1 : 0;
+    a.vec_store = (out_frames % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0 && out_frames * (int64_t)s.n_mel < ((int64_t)1 << 31)) ? 1 : 0;
     a.la = make_log_affine(s);
     a.window = plan.d_window;
     a.tw = reinterpret_cast<const float2*>(plan.d_tw_a);
