@@ -59,8 +59,10 @@ __device__ __forceinline__ float2 tw32(int k) {
 constexpr int kPrefetch = 4;     // float4 registers per thread for the next group's samples
 
 // One frame: 32 samples at xp (LDS) -> 17 magnitudes (or powers) at o[k * S] (LDS image of the output block).
-template <bool ALIGNED_HOP>
-__device__ __forceinline__ void stft32_frame(const StftArgs& p, const float* xp, float* o, int S) {
+// `o` is addressed with 32-bit offsets (k * S is wave-uniform), the magnitude / power choice is a compile-time constant: as run-time
+// values they cost a 64-bit multiply-add per stored bin and a select per stored bin.
+template <bool ALIGNED_HOP, bool MAGNITUDE>
+__device__ __forceinline__ void stft32_frame(const StftArgs& p, const float* xp, float* o, unsigned S) {
     float x[32];
     if (ALIGNED_HOP) {
 #pragma unroll
@@ -76,6 +78,11 @@ __device__ __forceinline__ void stft32_frame(const StftArgs& p, const float* xp,
 #pragma unroll
     for (int n = 0; n < 16; ++n) z[n] = make_float2(x[2 * n] * p.win[2 * n], x[2 * n + 1] * p.win[2 * n + 1]);
     fft16(z);
+    typedef __attribute__((address_space(3))) float lds_float;
+    lds_float* ol = (lds_float*)o;          // LDS pointer: 32-bit address arithmetic
+    // the optimiser must not see how `ol` was formed: it would fold k into the row term of the index ((17 r + k) * S + s) and pay a
+    // 64-bit multiply-add per stored bin, where k * S is a scalar and the sum is one addition
+    asm volatile("" : "+v"(ol));
 #pragma unroll
     for (int k = 0; k <= 8; ++k) {
         const float2 zk = z[fft16_pos(k)];
@@ -87,9 +94,9 @@ __device__ __forceinline__ void stft32_frame(const StftArgs& p, const float* xp,
         const float2 xa = cadd(E, G), xb = csub(E, G);
         float pa = xa.x * xa.x + xa.y * xa.y;
         float pb = xb.x * xb.x + xb.y * xb.y;
-        if (p.power == 1) { pa = __builtin_amdgcn_sqrtf(pa); pb = __builtin_amdgcn_sqrtf(pb); }
-        o[k * S] = pa;
-        if (k != 8) o[(16 - k) * S] = pb;
+        if (MAGNITUDE) { pa = __builtin_amdgcn_sqrtf(pa); pb = __builtin_amdgcn_sqrtf(pb); }
+        ol[(unsigned)k * S] = pa;
+        if (k != 8) ol[(unsigned)(16 - k) * S] = pb;
     }
 }
 
@@ -177,7 +184,8 @@ __global__ void __launch_bounds__(kMaxThreads) stft32_kernel(const StftArgs p) {
         for (int f = threadIdx.x; f < n_fr; f += nthr) {
             const int r = f / S;
             const int s = f - r * S;
-            stft32_frame<ALIGNED_HOP>(p, s_in + r * p.row_lds + s * p.hop, s_out + r * 17 * S + s, S);    // frame s covers samples [s*hop-16, s*hop+16)
+            if (p.power == 1) stft32_frame<ALIGNED_HOP, true>(p, s_in + r * p.row_lds + s * p.hop, s_out + r * 17 * S + s, (unsigned)S);
+            else stft32_frame<ALIGNED_HOP, false>(p, s_in + r * p.row_lds + s * p.hop, s_out + r * 17 * S + s, (unsigned)S);    // frame s covers samples [s*hop-16, s*hop+16)
         }
         lds_barrier();      // output image complete; every wave is done reading s_in
         // ---- stage the next group (its loads were issued a whole work phase ago), refill the prefetch --------
@@ -207,7 +215,7 @@ constexpr int kWsPrefetch = 6;   // float4 registers per mover lane for the samp
 // LDS holds two input buffers and two output images.  In step t a block's compute waves work on its t-th group
 // (input buffer t & 1 -> image t & 1) while its mover waves store image (t - 1) & 1, drop the samples of group t + 1
 // (requested one step earlier) into input buffer (t + 1) & 1 and request those of group t + 2; one barrier ends the step.
-template <bool NT>
+template <bool NT, bool MAGNITUDE>
 __global__ void __launch_bounds__(kMaxThreads) stft32_ws_kernel(const StftArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef float vf4 __attribute__((ext_vector_type(4)));
@@ -273,9 +281,9 @@ __global__ void __launch_bounds__(kMaxThreads) stft32_ws_kernel(const StftArgs p
                 float* s_out = s_out0 + (t & 1) * out_floats;
                 const int n_fr = rows * S;
                 for (int f = threadIdx.x; f < n_fr; f += n_compute) {
-                    const int r = (int)__umulhi((unsigned)f, p.inv_frames);
-                    const int fs = f - r * S;
-                    stft32_frame<true>(p, s_in + r * p.row_lds + fs * p.hop, s_out + r * 17 * S + fs, S);
+                    const unsigned r = __umulhi((unsigned)f, p.inv_frames);
+                    const unsigned fs = (unsigned)f - r * (unsigned)S;
+                    stft32_frame<true, MAGNITUDE>(p, s_in + (r * (unsigned)p.row_lds + fs * (unsigned)p.hop), s_out + (r * 17u * (unsigned)S + fs), (unsigned)S);
                 }
             }
         } else {
@@ -373,14 +381,15 @@ int stft32_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
                 a.vec_in = a.vec_out = 1;
                 const int threads = 64 * (compute + movers);
                 const size_t lds = (size_t)(2 * r_ws * per_row_bytes);
-                const bool nt = plan.tune_nt != 0;
-                const void* fn = nt ? reinterpret_cast<const void*>(&stft32_ws_kernel<true>) : reinterpret_cast<const void*>(&stft32_ws_kernel<false>);
-                const int rc = kernel_prepare(fn, threads, lds, &blocks_per_cu, &cus);
+                const bool nt = plan.tune_nt != 0, mag = s.power == 1;
+                typedef void (*ws_fn)(const StftArgs);
+                const ws_fn kfn = nt ? (mag ? &stft32_ws_kernel<true, true> : &stft32_ws_kernel<true, false>)
+                                     : (mag ? &stft32_ws_kernel<false, true> : &stft32_ws_kernel<false, false>);
+                const int rc = kernel_prepare(reinterpret_cast<const void*>(kfn), threads, lds, &blocks_per_cu, &cus);
                 if (rc) return rc;
                 const int64_t groups = (n_rows + r_ws - 1) / r_ws;
                 const int grid = (int)std::min<int64_t>(groups, (int64_t)cus * blocks_per_cu);
-                if (nt) hipLaunchKernelGGL(stft32_ws_kernel<true>, dim3(grid), dim3(threads), lds, stream, a);
-                else hipLaunchKernelGGL(stft32_ws_kernel<false>, dim3(grid), dim3(threads), lds, stream, a);
+                hipLaunchKernelGGL(kfn, dim3(grid), dim3(threads), lds, stream, a);
                 MMFE_HIP_CHECK(hipGetLastError());
                 return MMFE_OK;
             }
