@@ -352,13 +352,24 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, MMFE_FBANK_MIN_WAVES_PER_
     // and can leave exactly those outstanding.  At the top of the loop the same wait would also have to cover the path
     // from the prologue, i.e. drain every store of the previous iteration before any arithmetic starts.
     auto lane_sum = [&]() {
-        float s = 0.f;
+        if constexpr (PCM) {
+            // 16-bit samples: the sum of a lane's <= 32 samples stays below 2^24, so integer addition gives exactly the float sum
+            // (every float partial sum is exact too) and the samples are converted once, where they are unpacked
+            // (v_dot2c_i32_i16 with the constant pair (1, 1) adds both halves of a word to the running sum in one instruction)
+            typedef short i16x2 __attribute__((ext_vector_type(2)));
+            int s = 0;
 #pragma unroll
-        for (int a = 0; a < NA; ++a) {
-            const float2 v = In::unpack(nxt[a]);
-            s += v.x + v.y;
+            for (int a = 0; a < NA; ++a) s = __builtin_amdgcn_sdot2(__builtin_bit_cast(i16x2, nxt[a]), i16x2{1, 1}, s, false);
+            return (float)s;
+        } else {
+            float s = 0.f;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const float2 v = In::unpack(nxt[a]);
+                s += v.x + v.y;
+            }
+            return s;
         }
-        return s;
     };
     float dc_part = lane_sum();
 
