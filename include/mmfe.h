@@ -23,6 +23,11 @@
  *   kind MMFE_KIND_FRAME     frame_signal(signal, frame_length, hop_length, window) of
  *                            classification/vggsound/utils/transforms.py:19-61 (identical copies
  *                            under recognition/ and retrieval/).
+ *   kind MMFE_KIND_RESAMPLE  the sample-rate conversion in front of the path: librosa.load(file,
+ *                            sr=16000, duration=10) of classification/vggsound/dataset/vggsound.py:114
+ *                            and ffmpeg -ar 24000 of
+ *                            classification/recognition/dataset/extract_audio.py:6-13 (filter design,
+ *                            alignment and output length of scipy.signal.resample_poly).
  *
  * Conventions
  *   - Every function returns 0 on success and a negative MMFE_E* code on failure; the message is

@@ -7,7 +7,8 @@ Not part of the test suite (it takes a minute or two); it is the wide net behind
 tests/test_gpu_parity.py.  Every case prints one line; the script exits non-zero on the first case outside its
 tolerance.  Tolerances are those of the fixed tests: kaldi log-mel p99.9 <= 1e-4 and max <= 2e-3, log-mel
 (n_fft 400) max <= 1e-4, EPIC log spectrogram max <= 1e-4, HAR magnitudes max <= 1e-6, frame_signal exact,
-16-bit output equal to the rounded float32 output, 16-bit PCM input equal to the decoded float32 input.
+16-bit output equal to the rounded float32 output, 16-bit PCM input equal to the decoded float32 input, resampler max <= 4e-6
+(inputs up to full scale).
 """
 import os
 import sys
@@ -165,11 +166,59 @@ def case_frame(rng):
     return f"frame n={n} frame_length={fl} hop={hop} window={'yes' if w is not None else 'no'}", mx, mx, mx == 0.0
 
 
+def case_resample(rng):
+    rates = [(44100, 16000), (48000, 16000), (48000, 24000), (22050, 16000), (16000, 44100), (8000, 16000), (44100, 24000),
+             (32000, 16000), (44100, 8000), (96000, 44100), (11025, 16000), (16000, 48000), (44100, 48000)]
+    orig, target = rates[int(rng.integers(len(rates)))]
+    rows = int(rng.integers(1, 6))
+    n = int(rng.integers(1, 60000))
+    pcm = bool(rng.integers(2))
+    if pcm:
+        xi = rng.integers(-32768, 32768, size=(rows, n), dtype=np.int16)
+        x = xi.astype(np.float32) / 32768.0
+        dev_in = torch.from_numpy(xi).cuda()
+    else:
+        x = rng.uniform(-1, 1, size=(rows, n)).astype(np.float32)
+        dev_in = torch.from_numpy(x).cuda()
+    ref = O.resample_poly(x, orig, target)
+    got = mm.resample_batch(dev_in, orig, target).cpu().numpy()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    mx, p = stats(got - ref)
+    return f"resample {orig}->{target} rows={rows} n={n} {'pcm' if pcm else 'f32'}", mx, p, mx <= 4e-6
+
+
+def case_logmel_batch(rng):
+    """Several utterances per call: the waves of the n_fft 400 kernel cross row boundaries inside their octet ranges."""
+    rows = int(rng.integers(2, 40))
+    n = int(rng.integers(400, 30000))
+    hop = int(rng.choice([160, 160, 80, 128]))
+    x = np.stack([synth("noise0.1", n, int(rng.integers(1 << 30))) * float(rng.choice([1.0, 0.01, 1e-4])) for _ in range(rows)])
+    ref = np.stack([O.whisper_logmel(r, hop=hop) for r in x])
+    got = mm.logmel.log_mel_spectrogram(torch.from_numpy(x).cuda(), hop_length=hop).cpu().numpy()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    mx, p = stats(got - ref)
+    return f"logmelbatch[{mm.plans.last_kernel()}] rows={rows} n={n} hop={hop}", mx, p, mx <= 1e-4
+
+
+def case_har_batch(rng):
+    """Enough rows for several row groups per block of the wave-specialised STFT kernel, aligned and unaligned."""
+    t = int(rng.choice([192, 192, 64, 256, 100, 33]))
+    shape = (int(rng.integers(500, 6000)), int(rng.integers(1, 7)), t)
+    x = rng.standard_normal(shape).astype(np.float32)
+    nov = int(rng.choice([28, 28, 24, 16]))
+    ref = O.stft_mag(x, nperseg=32, noverlap=nov)
+    got = mm.stft_mag(x, nperseg=32, noverlap=nov)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    mx, p = stats(got - ref)
+    return f"harbatch[{mm.plans.last_kernel()}] {shape} noverlap={nov}", mx, p, mx <= 1e-6
+
+
 def main():
     cases = int(sys.argv[sys.argv.index("--cases") + 1]) if "--cases" in sys.argv else 200
     seed = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 0
     rng = np.random.default_rng(seed)
-    makers = [case_fbank, case_fbank, case_logmel, case_logmel, case_har, case_frame, case_epic, case_half, case_pcm, case_logspec, case_logspec]
+    makers = [case_fbank, case_fbank, case_logmel, case_logmel, case_har, case_frame, case_epic, case_half, case_pcm, case_logspec, case_logspec,
+              case_resample, case_resample, case_logmel_batch, case_har_batch]
     worst = {}
     for i in range(cases):
         fn = makers[i % len(makers)]
