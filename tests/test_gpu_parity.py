@@ -1239,3 +1239,15 @@ def test_frame_signal_plans_are_cached_by_window(mm, O):
     c = mm.frame_signal(x, 64, 16, w2.cuda())
     assert len(plans._plans) == n_plans + 1
     assert torch.equal(a.cpu(), O.frame_signal(x.cpu(), 64, 16, w1)) and torch.equal(c.cpu(), O.frame_signal(x.cpu(), 64, 16, w2))
+
+
+def test_vggsound_against_the_c_restatement(mm):
+    """The HIP path against the second, independent CPU restatement (oracle/fbank_ref.c: plain C, its own radix-2 FFT): same bar as
+    against the Python oracle."""
+    from oracle import fbank_ref
+    clips = np.stack([synth(k, 160000, 4321 + i) for i, k in enumerate(("noise0.1", "uniform", "quiet", "impulse"))])
+    ref = fbank_ref.preprocessing_audio_batch(clips, threads=4)
+    got = mm.preprocessing_audio_batch(torch.from_numpy(clips).cuda()).cpu().numpy()
+    mx, p999 = _stats(got - ref)
+    print("vs C restatement: max", mx, "p99.9", p999)
+    assert p999 <= 1e-4 and mx <= 2e-3
