@@ -533,9 +533,6 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
                         lmax = fmaxf(fmaxf(lmax, v[4 * st]), fmaxf(v[4 * st + 1], fmaxf(v[4 * st + 2], v[4 * st + 3])));
                         lmin = fminf(fminf(lmin, v[4 * st]), fminf(v[4 * st + 1], fminf(v[4 * st + 2], v[4 * st + 3])));
                     }
-#ifdef MMFE_ABL_NOSTORE      // diagnostic build: the stores stay in the code but never execute (no value is ever this bit pattern)
-                    if (__float_as_uint(v[4 * st]) != 0x7fc12345u) continue;
-#endif
                     *reinterpret_cast<float4*>(obase + coff[st]) = make_float4(v[4 * st], v[4 * st + 1], v[4 * st + 2], v[4 * st + 3]);
                 }
             }
@@ -557,9 +554,6 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
                     }
                     if (p.layout == MMFE_LAYOUT_FEAT_MAJOR) {
                         float* o = p.out + ((int64_t)cur_row * p.n_mel + m) * p.out_frames + tf;
-#ifdef MMFE_ABL_NOSTORE      // diagnostic build: the stores stay in the code but never execute (no value is ever this bit pattern)
-                        if (__float_as_uint(v[4 * st]) != 0x7fc12345u) continue;
-#endif
                         if (p.vec_store && tf + 4 <= p.frames_valid) {
                             *reinterpret_cast<float4*>(o) = make_float4(v[4 * st], v[4 * st + 1], v[4 * st + 2], v[4 * st + 3]);
                         } else {
