@@ -102,8 +102,9 @@ extern "C" {
 /* mmfe_spec.out_dtype: element type of the output tensor */
 #define MMFE_OUT_F32   0
 #define MMFE_OUT_F16   1  /* IEEE half, round to nearest even: what the encoders' @autocast() casts the spectrogram to
-                           (classification/vggsound/models/vit_model.py:388); n_fft 512 log-mel kernel only */
-#define MMFE_OUT_BF16  2  /* bfloat16, round to nearest even; n_fft 512 log-mel kernel only */
+                           (classification/vggsound/models/vit_model.py:388); FBANK and LOGSPEC kinds (the any-length DFT kernel not
+                           together with clamp_below_max) */
+#define MMFE_OUT_BF16  2  /* bfloat16, round to nearest even; same kinds */
 
 /* mmfe_spec.in_dtype: element type of the input rows */
 #define MMFE_IN_F32   0

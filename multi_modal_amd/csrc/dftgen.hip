@@ -52,6 +52,7 @@ struct DftArgs {
     float spec_scale;
     LogAffine la;          // log + affine stage (plain log when a clamp pass follows)
     int layout;
+    int out_dtype;         // MMFE_OUT_*: 16-bit kinds store the rounded value (what .to(dtype) of the float32 result gives)
     int p_alias;           // the power spectra reuse the LDS space of the staged taps
     const double* window;      // win_len doubles
     const double2* tw;         // n_fft entries exp(-2 pi i n / n_fft), float64
@@ -60,6 +61,12 @@ struct DftArgs {
     const int32_t* band_off;
     const float* band_w;
 };
+
+// One output element in the plan's output type (float32, or float16 / bfloat16 rounded to nearest even).
+__device__ __forceinline__ void store_out(const DftArgs& p, int64_t i, float v) {
+    if (p.out_dtype == MMFE_OUT_F32) p.out[i] = v;
+    else reinterpret_cast<unsigned short*>(p.out)[i] = p.out_dtype == MMFE_OUT_BF16 ? bf16_bits(v) : f16_bits(v);
+}
 
 template <typename S /* input element: float, or int16_t PCM decoded as s / 32768 */>
 __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
@@ -263,7 +270,7 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
             int64_t o;
             if (p.layout == MMFE_LAYOUT_FEAT_MAJOR) o = ((int64_t)row * nfeat + m) * p.out_frames + (t0 + f);
             else o = ((int64_t)row * p.out_frames + (t0 + f)) * nfeat + m;
-            p.out[o] = v;
+            store_out(p, o, v);
             if (p.rowmax != nullptr) local_max = fmaxf(local_max, v);      // clamp + affine happen in the second pass
         }
         if (p.rowmax != nullptr) {
@@ -292,7 +299,8 @@ __global__ void __launch_bounds__(kThreads) dftgen_kernel(const DftArgs p) {
 // tile live in L1/L2) and multiplies by the float64 window.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-template <typename S, int KS /* k-steps of 4 pairs */>
+template <typename S, int KS /* k-steps of 4 pairs */, bool OUT16 /* float16 / bfloat16 stores (a compile-time choice: as a run-time branch in
+                                                                  the epilogue it cost this kernel 4 %) */>
 __global__ void __launch_bounds__(kThreads, 2) dftmm_kernel(const DftArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2* s_tw = reinterpret_cast<double2*>(smem);                     // 2*n_fft half-step twiddles (cos, -sin)
@@ -413,7 +421,8 @@ __global__ void __launch_bounds__(kThreads, 2) dftmm_kernel(const DftArgs p) {
                 int64_t oi;
                 if (p.layout == MMFE_LAYOUT_FEAT_MAJOR) oi = ((int64_t)row * p.n_feat + bin) * p.out_frames + (t0 + f);
                 else oi = ((int64_t)row * p.out_frames + (t0 + f)) * p.n_feat + bin;
-                p.out[oi] = v[j];
+                if (OUT16) reinterpret_cast<unsigned short*>(p.out)[oi] = p.out_dtype == MMFE_OUT_BF16 ? bf16_bits(v[j]) : f16_bits(v[j]);
+                else p.out[oi] = v[j];
             }
         }
     }
@@ -424,16 +433,21 @@ __global__ void __launch_bounds__(kThreads, 2) dftmm_kernel(const DftArgs p) {
 #endif
 }
 
-template <typename S, int KS>
-int dftmm_launch_variant(const DftArgs& a, int64_t items, size_t lds, hipStream_t stream) {
+template <typename S, int KS, bool OUT16>
+int dftmm_launch_typed(const DftArgs& a, int64_t items, size_t lds, hipStream_t stream) {
     int resident = 1, cus = 256;
-    int rc = kernel_prepare(reinterpret_cast<const void*>(&dftmm_kernel<S, KS>), kThreads, lds, &resident, &cus);
+    int rc = kernel_prepare(reinterpret_cast<const void*>(&dftmm_kernel<S, KS, OUT16>), kThreads, lds, &resident, &cus);
     if (rc) return rc;
     const int64_t blocks = (items + kThreads / 64 - 1) / (kThreads / 64);
     const int grid = (int)std::min<int64_t>(blocks, (int64_t)cus * resident);
-    hipLaunchKernelGGL((dftmm_kernel<S, KS>), dim3(grid), dim3(kThreads), lds, stream, a);
+    hipLaunchKernelGGL((dftmm_kernel<S, KS, OUT16>), dim3(grid), dim3(kThreads), lds, stream, a);
     MMFE_HIP_CHECK(hipGetLastError());
     return MMFE_OK;
+}
+
+template <typename S, int KS>
+int dftmm_launch_variant(const DftArgs& a, int64_t items, size_t lds, hipStream_t stream) {
+    return a.out_dtype == MMFE_OUT_F32 ? dftmm_launch_typed<S, KS, false>(a, items, lds, stream) : dftmm_launch_typed<S, KS, true>(a, items, lds, stream);
 }
 
 // Plans the matrix-pipe form serves (MMFE_DFT_FORM=valu keeps them on the vector form).
@@ -568,6 +582,7 @@ int dftgen_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
     a.remove_dc = s.remove_dc; a.preemph = s.preemph; a.power = s.power; a.spec_scale = s.spec_scale;
     a.la = make_log_affine(s, s.clamp_below_max > 0.f);
     a.layout = s.layout;
+    a.out_dtype = s.out_dtype;
     a.window = plan.d_window64;
     a.tw = reinterpret_cast<const double2*>(plan.d_tw64);
     a.band_start = plan.d_band_start; a.band_len = plan.d_band_len; a.band_off = plan.d_band_off; a.band_w = plan.d_band_w;

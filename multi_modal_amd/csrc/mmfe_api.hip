@@ -164,7 +164,7 @@ int noalloc_scratch_ptr(int device, float** out) {
 
 int run_common(const Plan* plan, const RowSource& src, int64_t n_rows, int64_t n_samples, void* out_any, void* hip_stream,
                bool static_scratch = false) {
-    float* out = static_cast<float*>(out_any);      // every kernel family but the n_fft 512 one stores floats (checked at plan creation)
+    float* out = static_cast<float*>(out_any);      // float32, or the 16-bit type the plan stores (each launcher knows its plan's out_dtype)
     if (plan == nullptr) { set_error("plan is NULL"); return MMFE_EINVAL; }
     if (n_rows < 0 || n_samples < 0) { set_error("negative size"); return MMFE_EINVAL; }
     if (n_rows == 0) return MMFE_OK;
@@ -343,8 +343,9 @@ int mmfe_plan_create(const mmfe_spec* spec, const void* window, const int32_t* b
         default:
             rc = MMFE_EINVAL;
     }
-    if (rc == MMFE_OK && spec->out_dtype != MMFE_OUT_F32 && p->impl != IMPL_FBANK512) {
-        set_error("half-precision output is implemented by the n_fft 512 log-mel kernel only");
+    if (rc == MMFE_OK && spec->out_dtype != MMFE_OUT_F32 &&
+        !(p->impl == IMPL_FBANK512 || p->impl == IMPL_RFFT400 || (p->impl == IMPL_DFT_GENERIC && !(spec->clamp_below_max > 0.f)))) {
+        set_error("16-bit output is implemented by the log-mel / log-spectrogram kernels (n_fft 512, n_fft 400, any-length DFT without clamp_below_max)");
         rc = MMFE_EINVAL;
     }
     if (rc) { free_plan(p); return rc; }

@@ -87,6 +87,7 @@ struct Rfft400Args {
     int pad_mode;
     int n_mel;
     int layout;
+    int out_dtype;             // MMFE_OUT_*: 16-bit kinds store the rounded value (what .to(dtype) of the float32 result gives)
     int vec_store;             // feature-major rows may be stored 16 bytes at a time
     LogAffine la;
     const float* window;       // 400 floats: window pre-halved at win_off, zeros elsewhere
@@ -186,6 +187,16 @@ __device__ __forceinline__ S fetch_raw(const S* row, int i, int n, int pad_mode)
     int m = i % period;
     if (m < 0) m += period;
     return row[m < n ? m : period - m];
+}
+
+// One output element / four consecutive ones in the plan's output type; `i` counts elements.
+__device__ __forceinline__ void store1(const Rfft400Args& p, int64_t i, float v) {
+    if (p.out_dtype == MMFE_OUT_F32) p.out[i] = v;
+    else reinterpret_cast<unsigned short*>(p.out)[i] = p.out_dtype == MMFE_OUT_BF16 ? bf16_bits(v) : f16_bits(v);
+}
+__device__ __forceinline__ void store4(const Rfft400Args& p, int64_t i, float a, float b, float c, float d) {     // i % 4 == 0, base 16-byte aligned
+    if (p.out_dtype == MMFE_OUT_F32) *reinterpret_cast<float4*>(p.out + i) = make_float4(a, b, c, d);
+    else *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + i) = make_uint2(pack2_bits(a, b, p.out_dtype), pack2_bits(c, d, p.out_dtype));
 }
 
 template <typename SMP /* input element: float or int16_t PCM */, int HOP /* 160: specialised staging layout; 0: any hop <= 160 */,
@@ -524,7 +535,7 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
         apply_log_affine_block(v, p.la);
         if (p.layout == MMFE_LAYOUT_FEAT_MAJOR && p.vec_store && t0 + 8 <= p.frames_valid) {
             // whole octet, 16-byte feature-major stores (the regular case): no per-frame predicates, one 64-bit scalar base per pass
-            float* obase = p.out + ((int64_t)cur_row * p.n_mel * p.out_frames + t0);
+            const int64_t obase = (int64_t)cur_row * p.n_mel * p.out_frames + t0;
 #pragma unroll
             for (int st = 0; st < kStreams; ++st) {
                 if (kSteps[st] == 0) continue;
@@ -533,7 +544,7 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
                         lmax = fmaxf(fmaxf(lmax, v[4 * st]), fmaxf(v[4 * st + 1], fmaxf(v[4 * st + 2], v[4 * st + 3])));
                         lmin = fminf(fminf(lmin, v[4 * st]), fminf(v[4 * st + 1], fminf(v[4 * st + 2], v[4 * st + 3])));
                     }
-                    *reinterpret_cast<float4*>(obase + coff[st]) = make_float4(v[4 * st], v[4 * st + 1], v[4 * st + 2], v[4 * st + 3]);
+                    store4(p, obase + coff[st], v[4 * st], v[4 * st + 1], v[4 * st + 2], v[4 * st + 3]);
                 }
             }
         } else {
@@ -553,19 +564,19 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
                         }
                     }
                     if (p.layout == MMFE_LAYOUT_FEAT_MAJOR) {
-                        float* o = p.out + ((int64_t)cur_row * p.n_mel + m) * p.out_frames + tf;
+                        const int64_t o = ((int64_t)cur_row * p.n_mel + m) * p.out_frames + tf;
                         if (p.vec_store && tf + 4 <= p.frames_valid) {
-                            *reinterpret_cast<float4*>(o) = make_float4(v[4 * st], v[4 * st + 1], v[4 * st + 2], v[4 * st + 3]);
+                            store4(p, o, v[4 * st], v[4 * st + 1], v[4 * st + 2], v[4 * st + 3]);
                         } else {
 #pragma unroll
                             for (int i = 0; i < 4; ++i)
-                                if (tf + i < p.frames_valid) o[i] = v[4 * st + i];
+                                if (tf + i < p.frames_valid) store1(p, o + i, v[4 * st + i]);
                         }
                     } else {
-                        float* o = p.out + ((int64_t)cur_row * p.out_frames + tf) * p.n_mel + m;
+                        const int64_t o = ((int64_t)cur_row * p.out_frames + tf) * p.n_mel + m;
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            if (tf + i < p.frames_valid) o[(int64_t)i * p.n_mel] = v[4 * st + i];
+                            if (tf + i < p.frames_valid) store1(p, o + (int64_t)i * p.n_mel, v[4 * st + i]);
                     }
                 }
             }
@@ -590,7 +601,9 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
 // clamp_below_max on the finished features.  The affine map (x + shift) * scale with scale > 0 is monotone, so it
 // commutes with the clamp: out = max(out, rowmax_out - c * scale).  Rows whose minimum already clears the threshold
 // (any signal with less than c decades of dynamic range) are skipped, so the pass normally reads two ints per row.
-__global__ void __launch_bounds__(256) clamp_rows_kernel(float* out, const int* rowmax, const int* rowmin, int64_t per_row,
+// 16-bit outputs: rounding is monotone, so max(round(x), round(thr)) is the rounding of max(x, thr), the value a cast of the float32
+// result holds; the extremes were tracked on the unrounded values.
+__global__ void __launch_bounds__(256) clamp_rows_kernel(float* out, int out_dtype, const int* rowmax, const int* rowmin, int64_t per_row,
                                                          int n_rows, int chunks_per_row, float delta) {
     const int64_t n_work = (int64_t)n_rows * chunks_per_row;
     for (int64_t wk = blockIdx.x; wk < n_work; wk += gridDim.x) {
@@ -603,8 +616,18 @@ __global__ void __launch_bounds__(256) clamp_rows_kernel(float* out, const int* 
         if (!(mn < thr)) continue;
         const int64_t len = (per_row + chunks_per_row - 1) / chunks_per_row;
         const int64_t lo = (int64_t)chunk * len, hi = lo + len < per_row ? lo + len : per_row;
-        float* o = out + (int64_t)row * per_row;
-        for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) o[i] = fmaxf(o[i], thr);
+        if (out_dtype == MMFE_OUT_F32) {
+            float* o = out + (int64_t)row * per_row;
+            for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) o[i] = fmaxf(o[i], thr);
+        } else {
+            unsigned short* o = reinterpret_cast<unsigned short*>(out) + (int64_t)row * per_row;
+            const unsigned short tb = out_dtype == MMFE_OUT_BF16 ? bf16_bits(thr) : f16_bits(thr);
+            const float tr = out_dtype == MMFE_OUT_BF16 ? __uint_as_float((unsigned)tb << 16) : (float)__builtin_bit_cast(_Float16, tb);
+            for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+                const float x = out_dtype == MMFE_OUT_BF16 ? __uint_as_float((unsigned)o[i] << 16) : (float)__builtin_bit_cast(_Float16, o[i]);
+                if (x < tr) o[i] = tb;
+            }
+        }
     }
 }
 
@@ -790,6 +813,7 @@ int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64
     a.pad_mode = s.pad_mode;
     a.n_mel = s.n_mel;
     a.layout = s.layout;
+    a.out_dtype = s.out_dtype;
     a.vec_store = (out_frames % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0 && out_frames * (int64_t)s.n_mel < ((int64_t)1 << 31)) ? 1 : 0;
     a.la = make_log_affine(s);
     a.window = plan.d_window;
@@ -841,7 +865,7 @@ int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64
         const int64_t per_row = out_frames * (int64_t)s.n_mel;
         const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(64, per_row / 4096));
         const int grid = (int)std::min<int64_t>(n_rows * chunks, (int64_t)cus * 8);
-        hipLaunchKernelGGL(clamp_rows_kernel, dim3(grid), dim3(256), 0, stream, out, a.rowmax, a.rowmin, per_row, (int)n_rows, chunks,
+        hipLaunchKernelGGL(clamp_rows_kernel, dim3(grid), dim3(256), 0, stream, out, s.out_dtype, a.rowmax, a.rowmin, per_row, (int)n_rows, chunks,
                            s.clamp_below_max * s.out_scale);
         MMFE_HIP_CHECK(hipGetLastError());
     }

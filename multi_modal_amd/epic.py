@@ -15,7 +15,7 @@ import torch
 
 from . import _native as N
 from . import melbank
-from .plans import IN_CODES, cached_plan, require_gpu, run_rows, to_device_rows
+from .plans import IN_CODES, OUT_CODES, cached_plan, require_gpu, run_rows, to_device_rows
 
 N_FFT = 511               # epic_kitchen.py:119
 RESAMPLING_RATE = 24000   # epic_kitchen.py:77
@@ -23,8 +23,9 @@ HALF_SPAN_SEC = 0.639     # epic_kitchen.py:131-132
 EDGE_SEC = 1.279          # epic_kitchen.py:147,150
 
 
-def _logspec_plan(device: int, nperseg: int, hop: int, eps: float, out_scale: float, in_dtype: int = N.IN_F32) -> N.Plan:
-    key = ("epic", nperseg, hop, float(eps), float(out_scale), int(in_dtype))
+def _logspec_plan(device: int, nperseg: int, hop: int, eps: float, out_scale: float, in_dtype: int = N.IN_F32,
+                  out_dtype: int = N.OUT_F32) -> N.Plan:
+    key = ("epic", nperseg, hop, float(eps), float(out_scale), int(in_dtype), int(out_dtype))
 
     def build(dev: int) -> N.Plan:
         if nperseg > N_FFT:
@@ -32,7 +33,7 @@ def _logspec_plan(device: int, nperseg: int, hop: int, eps: float, out_scale: fl
         spec = N.make_spec(kind=N.KIND_LOGSPEC, n_fft=N_FFT, win_len=nperseg, win_off=(N_FFT - nperseg) // 2, hop=hop,
                            pad_mode=N.PAD_ZERO, frames_mode=N.FRAMES_CENTER, n_mel=0, power=2,
                            log_kind=N.LOG_LN_ADD, log_floor=float(eps), out_shift=0.0, out_scale=out_scale,
-                           layout=N.LAYOUT_FEAT_MAJOR, window_f64=1, in_dtype=in_dtype)
+                           layout=N.LAYOUT_FEAT_MAJOR, window_f64=1, in_dtype=in_dtype, out_dtype=out_dtype)
         win = melbank.periodic_hann(nperseg)      # float64, multiplied in float64 like librosa does
         return N.Plan(spec, win, device=dev)
 
@@ -47,16 +48,20 @@ def _params(window_size, step_size, resampling_rate):
 
 def log_specgram_batch(audio: torch.Tensor, window_size: int = 10, step_size: int = 5, eps: float = 1e-6,
                        resampling_rate: int = RESAMPLING_RATE, div255: bool = False,
-                       out: Optional[torch.Tensor] = None, lengths=None) -> torch.Tensor:
+                       out: Optional[torch.Tensor] = None, lengths=None, dtype: torch.dtype = torch.float32) -> torch.Tensor:
     """(B, n) slices -> (B, 256, 1 + (n-1)//hop) log power spectrograms (frequency-major), one launch.
     lengths: slices of different lengths in one batch (30 672-sample interior and 30 696-sample edge slices both give
     256 frames, epic_kitchen.py:143-154); row r is audio[r, :lengths[r]], zero-padded at its own end like librosa does.
     div255=True folds the ToTorchFormatTensor division in, giving what the encoder consumes.
     int16 input is the pcm_s16le audio the reference extracts (recognition/dataset/extract_audio.py:9), decoded in
-    the kernel as s / 32768 like librosa.load does (epic_kitchen.py:135)."""
+    the kernel as s / 32768 like librosa.load does (epic_kitchen.py:135).
+    dtype=torch.float16 / torch.bfloat16 stores the value `.to(dtype)` of the float32 result would give (what an encoder under
+    autocast casts its input to), rounded in the kernel."""
+    if dtype not in OUT_CODES:
+        raise TypeError(f"dtype must be float32, float16 or bfloat16, got {dtype}")
     x, origin = to_device_rows(audio, pcm_ok=True)
     nperseg, hop = _params(window_size, step_size, resampling_rate)
-    plan = _logspec_plan(x.device.index, nperseg, hop, eps, 1.0 / 255.0 if div255 else 1.0, IN_CODES[x.dtype])
+    plan = _logspec_plan(x.device.index, nperseg, hop, eps, 1.0 / 255.0 if div255 else 1.0, IN_CODES[x.dtype], OUT_CODES[dtype])
     y = run_rows(plan, x, out, lengths)
     return y if origin.type == "cuda" else y.to(origin)
 
@@ -101,13 +106,15 @@ def sound_slice_bounds(start_frame: int, idx: int, fps_spec: float, n_total: int
 
 def extract_sound_features(recordings: Sequence[torch.Tensor], rec_index: Sequence[int], start_frame: Sequence[int],
                            idx: Sequence[int], fps_spec: Sequence[float], resampling_rate: int = RESAMPLING_RATE,
-                           div255: bool = True) -> torch.Tensor:
+                           div255: bool = True, dtype: torch.dtype = torch.float32) -> torch.Tensor:
     """Batched _extract_sound_feature + _log_specgram (+ /255): for sample i the slice of
     recordings[rec_index[i]] around (start_frame[i] + idx[i]) / fps_spec[i] is transformed straight from
     the packed device-resident recordings (no per-slice copy).  Interior slices (30 672 samples) and edge slices
     (30 696) may be mixed, as a DataLoader batch of the reference mixes them: one launch serves all of them.
     Recordings that are all int16 stay 16-bit PCM on the device (half the memory) and are decoded in the kernel.
-    Returns (B, 1, 256, frames)."""
+    Returns (B, 1, 256, frames), float32 or (dtype) the float16 / bfloat16 rounding of it."""
+    if dtype not in OUT_CODES:
+        raise TypeError(f"dtype must be float32, float16 or bfloat16, got {dtype}")
     require_gpu()
     dev = torch.device("cuda", torch.cuda.current_device())
     pcm = len(recordings) > 0 and all(r.dtype == torch.int16 for r in recordings)
@@ -124,9 +131,9 @@ def extract_sound_features(recordings: Sequence[torch.Tensor], rec_index: Sequen
     n = max(sizes) if sizes else 0
     ragged = len(set(sizes)) > 1
     nperseg, hop = _params(10, 5, resampling_rate)
-    plan = _logspec_plan(dev.index, nperseg, hop, 1e-6, 1.0 / 255.0 if div255 else 1.0, IN_CODES[el])
+    plan = _logspec_plan(dev.index, nperseg, hop, 1e-6, 1.0 / 255.0 if div255 else 1.0, IN_CODES[el], OUT_CODES[dtype])
     frames, feat = plan.out_shape(n)
-    out = torch.empty((len(bounds), 1, feat, frames), dtype=torch.float32, device=dev)
+    out = torch.empty((len(bounds), 1, feat, frames), dtype=dtype, device=dev)
     if len(bounds) == 0 or frames == 0:
         return out
     d_start = torch.from_numpy(starts).to(dev)

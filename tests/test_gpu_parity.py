@@ -570,8 +570,34 @@ def test_vggsound_half_precision_output(mm, dtype):
     assert torch.equal(mm.preprocessing_audio_batch(short, dtype=dtype), mm.preprocessing_audio_batch(short).to(dtype))
     kw = dict(sample_frequency=16000, num_mel_bins=23, frame_shift=10.0)
     assert torch.equal(mm.fbank_batch(clips[:, :48000], dtype=dtype, **kw), mm.fbank_batch(clips[:, :48000], **kw).to(dtype))
-    with pytest.raises(mm.MmfeError, match="half-precision"):
-        mm.fbank_batch(clips[:, :48000], dtype=dtype, round_to_power_of_two=False, **kw)     # n_fft 400: float32 only
+    # n_fft 400 with DC removal and pre-emphasis runs on the any-length DFT kernel, which rounds in its stores as well
+    kw400 = dict(kw, round_to_power_of_two=False)
+    assert torch.equal(mm.fbank_batch(clips[:, :48000], dtype=dtype, **kw400), mm.fbank_batch(clips[:, :48000], **kw400).to(dtype))
+    kwr = dict(kw400, num_mel_bins=80, remove_dc_offset=False, preemphasis_coefficient=0.0)      # the radix n_fft 400 kernel
+    assert torch.equal(mm.fbank_batch(clips[:, :48000], dtype=dtype, **kwr), mm.fbank_batch(clips[:, :48000], **kwr).to(dtype))
+    assert mm.plans.last_kernel() == "rfft400"
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_epic_half_precision_output(mm, dtype):
+    """EPIC log-spectrograms stored as float16 / bfloat16 (the (B, 1, 256, 256) tensor an encoder under autocast would cast):
+    bit for bit the rounding of the float32 result, for the matrix-pipe form, the vector form (mel bank), mixed slice lengths
+    from packed recordings, and PCM input."""
+    x = torch.from_numpy(np.stack([synth(k, 30696, 300 + i) for i, k in enumerate(("noise0.1", "quiet", "sine+noise"))])).cuda()
+    ref = mm.log_specgram_batch(x, div255=True)
+    got = mm.log_specgram_batch(x, div255=True, dtype=dtype)
+    assert got.dtype == dtype and torch.equal(got, ref.to(dtype))
+    lens = [30672, 30696, 30672]
+    assert torch.equal(mm.log_specgram_batch(x, lengths=lens, dtype=dtype), mm.log_specgram_batch(x, lengths=lens).to(dtype))
+    recs = [torch.from_numpy(synth("noise0.1", 24000 * 8, 310)), torch.from_numpy(synth("uniform", 24000 * 5, 311))]
+    args = (recs, [0, 1, 0, 1], [0, 30, 150, 90], [0, 5, 20, 40], [60.0, 60.0, 60.0, 60.0])
+    a = mm.epic.extract_sound_features(*args)
+    b = mm.epic.extract_sound_features(*args, dtype=dtype)
+    assert b.shape == a.shape == (4, 1, 256, 256) and torch.equal(b, a.to(dtype))
+    pcm = (x * 32767.0).round().to(torch.int16)
+    assert torch.equal(mm.log_specgram_batch(pcm, dtype=dtype), mm.log_specgram_batch(pcm).to(dtype))
+    with pytest.raises(TypeError):
+        mm.log_specgram_batch(x, dtype=torch.float64)
 
 
 def test_cal_norm(mm):
@@ -1251,3 +1277,25 @@ def test_vggsound_against_the_c_restatement(mm):
     mx, p999 = _stats(got - ref)
     print("vs C restatement: max", mx, "p99.9", p999)
     assert p999 <= 1e-4 and mx <= 2e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_logmel_half_precision_output(mm, dtype):
+    """Long-utterance log-mel stored as float16 / bfloat16 = the rounding of the float32 features, bit for bit, with the per-row
+    clamp active (a loud burst in a quiet utterance), lengths that end in a partial octet, other hops, and PCM input."""
+    rng = np.random.default_rng(12)
+    x = (1e-5 * rng.standard_normal((5, 48000))).astype(np.float32)
+    x[:, 10000:12000] += 0.5 * rng.standard_normal((5, 2000)).astype(np.float32)
+    x = torch.from_numpy(x).cuda()
+    for n, hop in ((48000, 160), (47999, 160), (12345, 160), (16000, 128), (401, 37)):
+        ref = mm.logmel.log_mel_spectrogram(x[:, :n], hop_length=hop)
+        got = mm.logmel.log_mel_spectrogram(x[:, :n], hop_length=hop, dtype=dtype)
+        assert mm.plans.last_kernel() == "rfft400"
+        assert got.dtype == dtype and got.shape == ref.shape
+        assert torch.equal(got, ref.to(dtype)), (n, hop)
+    ref = mm.logmel.log_mel_spectrogram(x)
+    assert (ref.amin(dim=(1, 2)) >= ref.amax(dim=(1, 2)) - 2.0 - 1e-6).all() and (ref == ref.amin(dim=(1, 2), keepdim=True)).float().mean() > 0.2
+    pcm = (x * 32767.0).round().clamp(-32768, 32767).to(torch.int16)
+    assert torch.equal(mm.logmel.log_mel_spectrogram(pcm, dtype=dtype), mm.logmel.log_mel_spectrogram(pcm).to(dtype))
+    with pytest.raises(mm.MmfeError, match="16-bit output"):
+        mm.logmel.log_mel_spectrogram(x, precision="float64", dtype=dtype)       # any-length kernel with a clamp pass: float32 only
