@@ -112,7 +112,7 @@ extern "C" {
                            (classification/vggsound/dataset/vggsound.py:66) and librosa.load
                            (classification/recognition/dataset/epic_kitchen.py:135) make of the 16-bit FLAC / pcm_s16le
                            WAV files the reference stores (vggsound.py:120, recognition/dataset/extract_audio.py:9);
-                           FBANK and LOGSPEC kinds */
+                           FBANK, LOGSPEC and RESAMPLE kinds */
 
 typedef struct mmfe_spec {
     int32_t struct_size;   /* = sizeof(mmfe_spec) */
