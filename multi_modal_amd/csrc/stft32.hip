@@ -12,7 +12,7 @@
 // block is contiguous in global memory, so it is drained with 16-byte coalesced stores: the kernel
 // is bound by HBM writes (81 % of its traffic), and partial-line stores would waste them.
 //
-// Two kernels share that arithmetic.  stft32_ws_kernel (aligned, contiguous batches: the regular case) splits the
+// Two kernels share that arithmetic.  stft32_ws_kernel (packed batches, hop a multiple of 4: the regular case) splits the
 // waves of a block by role: compute waves turn the staged rows of group g into the output image of group g while a
 // few mover waves store the image of group g - 1 and stage the samples of group g + 1, both buffers doubled in LDS,
 // one barrier per group.  A wave that waits for the memory system to accept its stores then never holds up
@@ -46,6 +46,7 @@ struct StftArgs {
     int vec_out;         // every group's output block starts 16-byte aligned: drain with 16-byte stores
     int mover_waves;     // stft32_ws_kernel: the last `mover_waves` waves of a block store and stage, the others compute
     unsigned inv_frames; // ceil(2^32 / n_frames): (f * inv_frames) >> 32 == f / n_frames for the frame indices of a group
+    unsigned inv_samples; // ceil(2^32 / n_samples), for the sample indices of a group (stft32_ws_kernel, n_samples % 4 != 0)
     float win[kN];       // window pre-multiplied by 0.5 * spec_scale
 };
 
@@ -116,11 +117,11 @@ __global__ void __launch_bounds__(kMaxThreads) stft32_kernel(const StftArgs p) {
     const int R = p.rows_per_block;
     const int S = p.n_frames;
     const int T = p.n_samples;
+    const int T4 = T >> 2;
     float* s_in = reinterpret_cast<float*>(smem);                    // R * row_lds
     float* s_out = s_in + R * p.row_lds;                             // R * 17 * S
     const int n_groups = (p.n_rows + R - 1) / R;
     const int nthr = blockDim.x;
-    const int T4 = T >> 2;
     const bool prefetch = p.vec_in && R * T4 <= kPrefetch * nthr;
 
     for (int i = threadIdx.x; i < R * (p.row_lds - T); i += nthr) {   // zero margins: never overwritten
@@ -211,7 +212,8 @@ __global__ void __launch_bounds__(kMaxThreads) stft32_kernel(const StftArgs p) {
 
 constexpr int kWsPrefetch = 6;   // float4 registers per mover lane for the samples of the group after next
 
-// Wave-specialised form (rows contiguous and 16-byte aligned, hop a multiple of 4, group output blocks 16-byte aligned).
+// Wave-specialised form (rows packed back to back from a 16-byte aligned base, hop a multiple of 4, group output blocks 16-byte
+// aligned).
 // LDS holds two input buffers and two output images.  In step t a block's compute waves work on its t-th group
 // (input buffer t & 1 -> image t & 1) while its mover waves store image (t - 1) & 1, drop the samples of group t + 1
 // (requested one step earlier) into input buffer (t + 1) & 1 and request those of group t + 2; one barrier ends the step.
@@ -222,7 +224,6 @@ __global__ void __launch_bounds__(kMaxThreads) stft32_ws_kernel(const StftArgs p
     const int R = p.rows_per_block;
     const int S = p.n_frames;
     const int T = p.n_samples;
-    const int T4 = T >> 2;
     const int in_floats = R * p.row_lds;
     const int out_floats = R * 17 * S;
     float* s_in0 = reinterpret_cast<float*>(smem);                   // 2 * R * row_lds
@@ -241,27 +242,48 @@ __global__ void __launch_bounds__(kMaxThreads) stft32_ws_kernel(const StftArgs p
         s_in0[r * p.row_lds + j] = 0.f;
     }
 
+    // A group's samples are one contiguous run of rows * T floats that starts 16-byte aligned (R is a multiple of 4), whatever T
+    // is; lanes take whole 16-byte pieces of the run.  With T % 4 != 0 a piece may straddle two rows, and the batch's last piece
+    // may be partial: that one is read float by float when it is staged, so that nothing is read beyond the batch.
+    const bool rows_split_pieces = (T & 3) != 0;
     vf4 pf[kWsPrefetch];
     auto fetch = [&](int grp) {                                      // movers: request group grp's samples
         const int row0 = grp * R;
-        const int rows = min(R, p.n_rows - row0);
+        const int n_el = grp < n_groups ? min(R, p.n_rows - row0) * T : 0;
         const vf4* g4 = reinterpret_cast<const vf4*>(gin + (int64_t)row0 * T);
 #pragma unroll
         for (int q = 0; q < kWsPrefetch; ++q) {
             const int i = ml + q * n_mover;
-            pf[q] = (grp < n_groups && i < rows * T4) ? __builtin_nontemporal_load(g4 + i) : vf4{0.f, 0.f, 0.f, 0.f};
+            pf[q] = 4 * i + 4 <= n_el ? __builtin_nontemporal_load(g4 + i) : vf4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto stage = [&](int grp, float* s_in) {                         // movers: registers -> LDS rows
         if (grp >= n_groups) return;
-        const int rows = min(R, p.n_rows - grp * R);
+        const int n_el = min(R, p.n_rows - grp * R) * T;
 #pragma unroll
         for (int q = 0; q < kWsPrefetch; ++q) {
-            const int i = ml + q * n_mover;
-            if (i < rows * T4) {
-                const int r = i / T4;
-                const int j4 = i - r * T4;
-                *reinterpret_cast<vf4*>(s_in + r * p.row_lds + 16 + 4 * j4) = pf[q];
+            const int e = 4 * (ml + q * n_mover);
+            if (e >= n_el) continue;
+            if (!rows_split_pieces) {
+                const unsigned r = __umulhi((unsigned)e, p.inv_samples);
+                *reinterpret_cast<vf4*>(s_in + r * (unsigned)p.row_lds + 16 + ((unsigned)e - r * (unsigned)T)) = pf[q];
+            } else {
+                unsigned r = __umulhi((unsigned)e, p.inv_samples);
+                unsigned j = (unsigned)e - r * (unsigned)T;
+                float* d = s_in + r * (unsigned)p.row_lds + 16;
+                if (e + 4 > n_el) {                                  // the batch's last, partial piece (one lane, once per launch)
+                    const float* g = gin + (int64_t)grp * R * T + e;
+                    for (int k = 0; k < n_el - e; ++k) {
+                        d[j] = g[k];
+                        if (++j == (unsigned)T) { j = 0; d += p.row_lds; }
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    d[j] = pf[q][k];
+                    if (++j == (unsigned)T) { j = 0; d += p.row_lds; }
+                }
             }
         }
     };
@@ -358,24 +380,26 @@ int stft32_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
     const int need = (int)((n_frames - 1) * s.hop + kN);
     a.row_lds = (std::max(need, (int)n_samples + 16) + 3) & ~3;
     const int64_t per_row_bytes = ((int64_t)a.row_lds + 17 * n_frames) * 4;
-    const bool contiguous = src.offsets == nullptr && src.stride == n_samples && n_samples % 4 == 0 &&
-                            reinterpret_cast<uintptr_t>(src.base) % 16 == 0;
+    const bool packed = src.offsets == nullptr && src.stride == n_samples && reinterpret_cast<uintptr_t>(src.base) % 16 == 0;
+    const bool contiguous = packed && n_samples % 4 == 0;      // every row starts 16-byte aligned
     const bool aligned_hop = s.hop % 4 == 0;
     a.inv_frames = (unsigned)(((uint64_t)1 << 32) / (uint64_t)n_frames + 1);
+    a.inv_samples = (unsigned)(((uint64_t)1 << 32) / (uint64_t)n_samples + 1);
     int blocks_per_cu = 1, cus = 256;
 
     // ---- wave-specialised form: two input buffers + two output images in LDS -------------------------------------
     // R: the largest multiple of 4 (16-byte aligned output blocks) whose doubled buffers fit; the compute waves cover a
     // group's R * S frames in as few passes as 16 - movers waves allow, the movers' prefetch registers must hold a group.
-    if (contiguous && aligned_hop && reinterpret_cast<uintptr_t>(out) % 16 == 0 && n_rows < ((int64_t)1 << 30) && plan.tune_chunk >= 0) {
+    if (packed && aligned_hop && reinterpret_cast<uintptr_t>(out) % 16 == 0 && n_rows < ((int64_t)1 << 30) && plan.tune_chunk >= 0) {
         int r_ws = (int)std::min<int64_t>(64, (150 * 1024) / (2 * per_row_bytes)) & ~3;
         if (plan.tune_blocks_per_cu >= 4 && plan.tune_blocks_per_cu % 4 == 0 && plan.tune_blocks_per_cu < r_ws) r_ws = plan.tune_blocks_per_cu;
-        if (r_ws >= 4 && n_frames >= 2 && (int64_t)r_ws * n_frames < 65536) {     // (the reciprocal division needs 2 <= S, R * S < 2^16)
+        // (the reciprocal divisions need 2 <= S, R * S < 2^16, and the same of the samples)
+        if (r_ws >= 4 && n_frames >= 2 && (int64_t)r_ws * n_frames < 65536 && n_samples >= 2 && (int64_t)r_ws * n_samples < 65536) {
             const int pass_waves = (int)(((int64_t)r_ws * n_frames + 63) / 64);       // compute waves for one pass
             int movers = pass_waves <= 12 ? 4 : (pass_waves == 13 ? 3 : (pass_waves == 14 ? 2 : 4));
             if (plan.tune_chunk >= 1 && plan.tune_chunk <= 8) movers = plan.tune_chunk;
             const int compute = std::min(pass_waves, 16 - movers);
-            if ((int64_t)r_ws * (n_samples / 4) <= (int64_t)kWsPrefetch * 64 * movers) {
+            if (((int64_t)r_ws * n_samples + 3) / 4 <= (int64_t)kWsPrefetch * 64 * movers) {
                 a.rows_per_block = r_ws;
                 a.mover_waves = movers;
                 a.vec_in = a.vec_out = 1;

@@ -63,7 +63,8 @@ def main():
     elif args.config == "logmel":
         rows, n, oshape = args.batch or 1024, 480000, (80, 3000)
     else:
-        rows, n, oshape = 6 * (args.batch or 262144), 192, (17, 49)
+        n = args.samples if args.samples != 160000 else 192          # --samples: window length (default 192)
+        rows, oshape = 6 * (args.batch or 262144), (17, 1 + (n + 3) // 4)
     x = torch.empty(rows, n, device=dev)
     slab = max(1, (1 << 28) // n)
     for lo in range(0, rows, slab):

@@ -403,6 +403,26 @@ def test_har_many_groups_per_block(mm, O):
     assert torch.equal(mm.stft_mag(shifted), got)
 
 
+@pytest.mark.parametrize("t", [190, 191, 193, 50, 34])
+def test_har_row_lengths_not_multiple_of_4(mm, O, t):
+    """Packed rows whose length is not a multiple of 4 samples: the 16-byte pieces a group's samples arrive in straddle rows, the
+    batch's last piece is partial (read float by float: nothing beyond the batch is touched), the last group is not full; a
+    strided view of the same rows goes through the phase-serial kernel and must give the same bits."""
+    g = np.random.default_rng(1000 + t)
+    n = 4099
+    x = g.standard_normal((n, t)).astype(np.float32)
+    ref = O.stft_mag(x)
+    guard = torch.full((n * t + 64,), float("nan"), device="cuda")          # NaNs right behind the batch: a read past its end shows
+    packed = guard[: n * t].view(n, t)
+    packed.copy_(torch.from_numpy(x))
+    got = mm.stft_mag(packed)
+    assert got.shape == ref.shape
+    assert np.abs(got.cpu().numpy() - ref).max() <= 1e-6
+    wide = torch.zeros(n, t + 3, device="cuda")
+    wide[:, :t] = packed
+    assert torch.equal(mm.stft_mag(wide[:, :t]), got)
+
+
 def test_har_against_scipy(mm):
     import scipy.signal
     rng = np.random.default_rng(11)
