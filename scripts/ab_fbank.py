@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--launches", type=int, default=20)
     ap.add_argument("--samples", type=int, default=160000)
+    ap.add_argument("--pcm", action="store_true", help="vgg / logmel: 16-bit PCM input")
     ap.add_argument("builds", nargs="+", help="name=path pairs")
     args = ap.parse_args()
     torch.cuda.set_device(0)
@@ -69,6 +70,8 @@ def main():
     slab = max(1, (1 << 28) // n)
     for lo in range(0, rows, slab):
         x[lo:lo + slab] = (0.1 * torch.randn(min(slab, rows - lo), n, device=dev, generator=g)).clamp_(-1, 1)
+    if args.pcm:
+        x = (x * 32767.0).round().to(torch.int16)
     names, plist, outs = [], [], []
     for b in args.builds:
         name, path = b.split("=", 1)
@@ -79,7 +82,7 @@ def main():
             saved[k] = os.environ.get(k)
             os.environ[k] = v
         names.append(name)
-        plist.append(build_plan(os.path.abspath(path), 0, config=args.config))
+        plist.append(build_plan(os.path.abspath(path), 0, in_dtype=N.IN_S16 if args.pcm else N.IN_F32, config=args.config))
         for k, v in saved.items():
             if v is None:
                 del os.environ[k]

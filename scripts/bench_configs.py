@@ -16,10 +16,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import multi_modal_amd as mm  # noqa: E402
 
 
-def timeit(fn, iters, warmup=3):
+def timeit(fn, iters, warmup=3, precondition=0.3):
+    """Average and minimum launch time in ms over `iters` launches, after `precondition` seconds of untimed launches: the first
+    launches after an idle period or after another configuration run at a different clock and say little about the steady rate."""
+    import time
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < precondition:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     for s, e in ev:
         s.record()
