@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(kThreads) resample_kernel(const ResampleArgs p
         __syncthreads();                                   // the previous tile's readers are done (and the bank is in place)
         for (int i = threadIdx.x; i < p.tile_in; i += kThreads) {
             const int64_t g = i_lo + i;
-            s_x[i] = (g >= 0 && g < n_row) ? sample_value(x[g]) : 0.f;
+            s_x[i] = (g >= 0 && g < n_row) ? sample_value(__builtin_nontemporal_load(x + g)) : 0.f;
         }
         __syncthreads();
         float* orow = p.out + (int64_t)row * p.out_stride;
@@ -106,9 +106,8 @@ __global__ void __launch_bounds__(kThreads) resample_kernel(const ResampleArgs p
 
 
 // ---- wave-uniform-phase kernel --------------------------------------------------------------------------------------
-constexpr int kQ = 4;                    // consecutive outputs per lane
 constexpr int kMaxPhaseThreads = 1024;
-constexpr int kPhasePF = 36;             // prefetch registers per thread (samples of the next tile)
+constexpr int kPhasePF = 36;             // samples of the next tile held per thread (9 four-sample pieces in the vector form)
 constexpr int kPhaseLdsBytes = 158 * 1024;
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
@@ -123,21 +122,39 @@ struct ResamplePhaseArgs {
     int64_t n_out;             // outputs computed per row
     int64_t out_stride;
     int up, down;
-    int L;                     // outputs between neighbouring lanes (a multiple of up and of kQ)
+    int L;                     // outputs between neighbouring lanes (a multiple of up and of Q)
     int D;                     // input samples between neighbouring lanes: L * down / up
     int nb;                    // lane blocks (64 lanes each) per tile
-    int groups;                // L / kQ: runs of kQ consecutive outputs inside L
+    int groups;                // L / Q: runs of Q consecutive outputs inside L
     int wlen;                  // window samples walked per run (a multiple of 8)
     int tile_in;               // staged input samples per tile
     int tile_out;              // nb * 64 * L
-    int ls;                    // floats between the output runs of neighbouring lanes in LDS (L, padded for conflict-free 16-byte writes)
+    int ls;                    // floats between the output runs of neighbouring lanes in LDS (L, padded: a multiple of 4 whose quarter is odd)
     int tiles_per_row;
     int vec_out;               // output rows start 16-byte aligned: whole tiles are stored 16 bytes per lane
-    const float* wt;           // [groups][wlen / 8][kQ][8]: weight of window sample s for output q of the run, zero outside its taps
+    const float* wt;           // [groups][wlen / 8][Q][8]: weight of window sample s for output q of the run, zero outside its taps
     const int* gi;             // [groups]: input offset of window sample 0 of the run
 };
 
-template <typename SMP>
+// four consecutive samples as they lie in memory
+template <typename SMP> struct Piece;
+template <> struct Piece<float> {
+    typedef f32x4 type;
+    static __device__ __forceinline__ f32x4 decode(f32x4 v) { return v; }
+};
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <> struct Piece<int16_t> {
+    typedef u32x2 type;
+    static __device__ __forceinline__ f32x4 decode(u32x2 v) {
+        constexpr float k = 1.0f / 32768.0f;
+        return f32x4{(float)(int16_t)(v.x & 0xffffu) * k, (float)((int32_t)v.x >> 16) * k, (float)(int16_t)(v.y & 0xffffu) * k, (float)((int32_t)v.y >> 16) * k};
+    }
+};
+
+// Q: consecutive outputs per lane.  VEC: rows start on 4-sample boundaries of suitably aligned memory and hold a multiple of 4
+// samples each (no per-row lengths); every tile's staged range starts at a multiple of 4 samples by construction, so the input
+// moves in whole four-sample pieces (16-byte / 8-byte loads, 16-byte LDS writes, one in-row test per piece).
+template <typename SMP, int Q, bool VEC>
 __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const ResamplePhaseArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_x = reinterpret_cast<float*>(smem);                       // tile_in (rounded up to 4)
@@ -147,8 +164,11 @@ __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const 
     const int n_waves = blockDim.x >> 6;
     const unsigned n_tiles = (unsigned)p.n_rows * (unsigned)p.tiles_per_row;      // < 2^31 (checked by the launcher)
     const int chunks = p.wlen >> 3;
+    typedef typename Piece<SMP>::type piece_t;
+    constexpr int kPieces = kPhasePF / 4;
 
-    SMP pf[kPhasePF];
+    SMP pf[VEC ? 1 : kPhasePF];
+    piece_t pv[VEC ? kPieces : 1];
     // tile -> (row, first output); staged sample k of a tile is input sample lo + k of the row
     auto fetch = [&](unsigned tile) {
         if (tile >= n_tiles) return;
@@ -157,61 +177,31 @@ __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const 
         const int lo = (m0 / p.up) * p.down - p.wlen;
         const SMP* x = row_ptr_as<SMP>(p.src, row);
         const int n_row = row_samples(p.src, row, p.n_in);
+        // every load reads inside the row (index clamped); samples outside the row are zeroed when the registers are staged, so
+        // that nothing here waits for the loads
+        if (VEC) {
+#pragma unroll
+            for (int q = 0; q < kPieces; ++q) {
+                const int g = lo + 4 * ((int)threadIdx.x + q * (int)blockDim.x);
+                // non-temporal: the input streams through once; cached, it pushes the filter weights out of L2 and every scalar-cache
+                // miss of the multiply-add loop then goes to memory (float32 input: 0.86 ms per 1024 clips cached, 0.66 non-temporal)
+                pv[q] = __builtin_nontemporal_load(reinterpret_cast<const piece_t*>(x + (g < 0 ? 0 : (g + 4 <= n_row ? g : n_row - 4))));
+            }
+            return;
+        }
         if (n_row <= 0) {            // block-uniform
 #pragma unroll
             for (int q = 0; q < kPhasePF; ++q) pf[q] = SMP(0);      // (staged as zeros whatever they hold: every index is outside the row)
             return;
         }
-        // every load reads inside the row (index clamped); samples outside the row are zeroed when the registers are staged, so
-        // that nothing here waits for the loads
 #pragma unroll
         for (int q = 0; q < kPhasePF; ++q) {
             const int g = lo + (int)threadIdx.x + q * (int)blockDim.x;
-            pf[q] = x[g < 0 ? 0 : (g < n_row ? g : n_row - 1)];
+            pf[q] = __builtin_nontemporal_load(x + (g < 0 ? 0 : (g < n_row ? g : n_row - 1)));
         }
     };
-    fetch(blockIdx.x);
-    for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const unsigned row = tile / (unsigned)p.tiles_per_row;
-        const int m0 = (int)(tile - row * (unsigned)p.tiles_per_row) * p.tile_out;
-        // ---- stage: registers -> LDS (the previous tile's readers passed the barrier that ended its drain) ----
-        {
-            const int lo = (m0 / p.up) * p.down - p.wlen;
-            const int n_row = row_samples(p.src, row, p.n_in);
-#pragma unroll
-            for (int q = 0; q < kPhasePF; ++q) {
-                const int k = threadIdx.x + q * blockDim.x;
-                const int g = lo + k;
-                if (k < p.tile_in) s_x[k] = (g >= 0 && g < n_row) ? sample_value(pf[q]) : 0.f;
-            }
-        }
-        lds_barrier();
-        fetch(tile + gridDim.x);                                        // in flight under the arithmetic below
-        // ---- runs: (lane block, group) pairs spread over the waves ----
-        for (int task = wave; task < p.nb * p.groups; task += n_waves) {
-            const int blk = task / p.groups;
-            const int u = task - blk * p.groups;
-            const float* xl = s_x + p.wlen + (blk * 64 + lane) * p.D + ((const_int*)p.gi)[u];
-            const_f32x8* w = ((const_f32x8*)p.wt) + (int64_t)u * chunks * kQ;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            // (requesting the next chunk's weights and samples ahead of the multiply-adds, in a second register set, measured the
-            // same: scalar loads and LDS reads share one counter and scalar loads return out of order, so any wait is a wait for
-            // everything, and the other waves of the SIMD already fill the gaps)
-            for (int c = 0; c < chunks; ++c) {
-                const f32x8 w0 = w[c * kQ], w1 = w[c * kQ + 1], w2 = w[c * kQ + 2], w3 = w[c * kQ + 3];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float xv = xl[-(c * 8 + e)];
-                    a0 = fmaf(w0[e], xv, a0);
-                    a1 = fmaf(w1[e], xv, a1);
-                    a2 = fmaf(w2[e], xv, a2);
-                    a3 = fmaf(w3[e], xv, a3);
-                }
-            }
-            *reinterpret_cast<f32x4*>(s_o + (blk * 64 + lane) * p.ls + kQ * u) = f32x4{a0, a1, a2, a3};
-        }
-        lds_barrier();
-        // ---- drain: lane run j holds outputs m0 + j * L .. + L - 1 ----
+    // ---- drain: lane run j holds outputs m0 + j * L .. + L - 1 of `row` ----
+    auto drain = [&](unsigned row, int m0) {
         float* orow = p.out + (int64_t)row * p.out_stride;
         if (p.ls == p.L) {
             for (int k = threadIdx.x; k < p.tile_out; k += blockDim.x) {
@@ -233,6 +223,77 @@ __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const 
                 }
             }
         }
+    };
+    fetch(blockIdx.x);
+    for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const unsigned row = tile / (unsigned)p.tiles_per_row;
+        const int m0 = (int)(tile - row * (unsigned)p.tiles_per_row) * p.tile_out;
+        // ---- stage: registers -> LDS (the previous tile's readers passed the barrier that ended its multiply-adds; its drain
+        //      reads the other LDS area) ----
+        {
+            const int lo = (m0 / p.up) * p.down - p.wlen;
+            const int n_row = row_samples(p.src, row, p.n_in);
+            if (VEC) {
+#pragma unroll
+                for (int q = 0; q < kPieces; ++q) {
+                    const int k = 4 * ((int)threadIdx.x + q * (int)blockDim.x);
+                    const int g = lo + k;
+                    const f32x4 v = Piece<SMP>::decode(pv[q]);
+                    if (k < p.tile_in) *reinterpret_cast<f32x4*>(s_x + k) = (g >= 0 && g + 4 <= n_row) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < kPhasePF; ++q) {
+                    const int k = threadIdx.x + q * blockDim.x;
+                    const int g = lo + k;
+                    if (k < p.tile_in) s_x[k] = (g >= 0 && g < n_row) ? sample_value(pf[q]) : 0.f;
+                }
+            }
+        }
+        lds_barrier();
+        fetch(tile + gridDim.x);                                        // in flight under the arithmetic below (requested after the
+                                                                        // first run instead: 3 % slower)
+        // ---- runs: (lane block, group) pairs spread over the waves ----
+        for (int task = wave; task < p.nb * p.groups; task += n_waves) {
+            const int blk = task / p.groups;
+            const int u = task - blk * p.groups;
+            const float* xl = s_x + p.wlen + (blk * 64 + lane) * p.D + ((const_int*)p.gi)[u];
+#ifdef MMFE_RS_ABL_SAMEW      // diagnostic build: every run reads group 0's weights (wrong results; shows what scalar-cache misses cost)
+            const_f32x8* w = ((const_f32x8*)p.wt);
+#else
+            const_f32x8* w = ((const_f32x8*)p.wt) + (int64_t)u * chunks * Q;
+#endif
+            float acc[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) acc[q] = 0.f;
+            // (requesting the next chunk's weights and samples ahead of the multiply-adds, in a second register set, measured 3 %
+            // slower: scalar loads and LDS reads share one counter and scalar loads return out of order, so any wait is a wait for
+            // everything, and the other waves of the SIMD already fill the gaps)
+            // (skipping, in the window's first and last chunks, the outputs that have no taps there - 13 % of the multiply-adds - measured
+            // 5 to 23 % slower: the wave-uniform branches cost the loop its overlap of loads and arithmetic)
+            for (int c = 0; c < chunks; ++c) {
+                f32x8 wq[Q];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) wq[q] = w[c * Q + q];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xv = xl[-(c * 8 + e)];
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) acc[q] = fmaf(wq[q][e], xv, acc[q]);
+                }
+            }
+            float* so = s_o + (blk * 64 + lane) * p.ls + Q * u;
+            if (Q == 4) {
+                *reinterpret_cast<f32x4*>(so) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+            } else {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) so[q] = acc[q];
+            }
+        }
+        lds_barrier();
+        // (storing a tile's outputs one step later instead - after the next tile is staged and before its samples' successors are
+        // requested, so that no stage ever waits behind stores - measured 6 % (16-bit input) to 16 % (float32) slower)
+        drain(row, m0);
         // (no barrier here: the next step's stage only writes s_x, whose readers passed the barrier above, and s_o is not written
         // again before the barrier that follows the stage)
     }
@@ -273,55 +334,69 @@ int resample_prepare(Plan& plan) {
     int rc = upload(&plan.d_window, bank);
     if (rc) return rc;
 
-    // ---- wave-uniform-phase kernel: applicable when lanes L = up * ceil(kQ / up) outputs apart leave whole runs of kQ ----
+    // ---- wave-uniform-phase kernel: applicable when lanes L = up * ceil(Q / up) outputs apart leave whole runs of Q ----
     plan.rs_L = 0;
     const char* force = std::getenv("MMFE_RESAMPLE_FORM");          // tuning / test knob, read once per plan: "general" forces the general kernel
     if (force != nullptr && std::string(force) == "general") return MMFE_OK;
-    const int64_t L = (int64_t)up * ((kQ + up - 1) / up);
-    if (L % kQ != 0 || L > 4096) return MMFE_OK;
-    const int64_t D = L * down / up;
-    const int groups = (int)(L / kQ);
+    const char* force_q = std::getenv("MMFE_RESAMPLE_Q");           // tuning knob, read once per plan: outputs per lane run (4 or 5)
     const int pre = (half + pre_pad) / down;
-    std::vector<int32_t> gi(groups);
-    std::vector<int> io(groups * kQ), ph(groups * kQ);
-    int max_back = 0, i_max = 0;
-    for (int u = 0; u < groups; ++u) {
-        for (int q = 0; q < kQ; ++q) {
-            const int64_t t = (int64_t)(kQ * u + q + pre) * down;
-            io[u * kQ + q] = (int)(t / up);
-            ph[u * kQ + q] = (int)(t % up);
-        }
-        gi[u] = io[u * kQ + kQ - 1];
-        i_max = std::max(i_max, gi[u]);
-        max_back = std::max(max_back, gi[u] - io[u * kQ]);
-    }
-    const int wlen = (taps + max_back + 7) & ~7;
-    std::vector<float> wt((size_t)groups * wlen * kQ, 0.f);
-    for (int u = 0; u < groups; ++u)
-        for (int sidx = 0; sidx < wlen; ++sidx)
-            for (int q = 0; q < kQ; ++q) {
-                const int t = sidx - (gi[u] - io[u * kQ + q]);
-                if (t >= 0 && t < taps)
-                    wt[(((size_t)u * (wlen / 8) + sidx / 8) * kQ + q) * 8 + sidx % 8] = bank[(size_t)ph[u * kQ + q] * taps_padded + t];
+    // Q = 4 or 5 consecutive outputs per lane: whichever fills the rounds of a block's waves better.  The multiply-adds of a
+    // tile take `rounds` turns of (waves per SIMD) runs of wlen * Q each.
+    struct Layout { int Q = 0, L = 0, D = 0, groups = 0, wlen = 0, i_max = 0, nb = 0, threads = 0, tile_in = 0, ls = 0; double cost = 0; std::vector<int32_t> gi; std::vector<int> io, ph; };
+    Layout best;
+    for (int Q = 4; Q <= 5; ++Q) {
+        if (force_q != nullptr && std::atoi(force_q) != Q) continue;
+        Layout c;
+        c.Q = Q;
+        const int64_t L = (int64_t)up * ((Q + up - 1) / up);
+        if (L % Q != 0 || L % 4 != 0 || L > 4096) continue;
+        c.L = (int)L;
+        c.D = (int)(L * down / up);
+        c.groups = (int)(L / Q);
+        c.gi.resize(c.groups);
+        c.io.resize(c.groups * Q);
+        c.ph.resize(c.groups * Q);
+        int max_back = 0;
+        for (int u = 0; u < c.groups; ++u) {
+            for (int q = 0; q < Q; ++q) {
+                const int64_t t = (int64_t)(Q * u + q + pre) * down;
+                c.io[u * Q + q] = (int)(t / up);
+                c.ph[u * Q + q] = (int)(t % up);
             }
-    // lane runs in the output area: a stride whose quarter is odd keeps the 16-byte writes of 64 lanes on distinct banks
-    const int ls = (L / 4) % 2 == 1 ? (int)L : (int)L + 4;
-    // lane blocks per tile: as many as LDS and the prefetch registers hold
-    int nb = 0, threads = 0, tile_in = 0;
-    for (int cand = 1; cand <= 64; ++cand) {
-        const int64_t t_in = wlen + (int64_t)cand * 64 * D + i_max + 1;
-        const int64_t bytes = 4 * (((t_in + 3) & ~(int64_t)3) + (int64_t)cand * 64 * ls);
-        const int tasks = cand * groups;
-        const int rounds = (tasks + 15) / 16;
-        const int nw = (tasks + rounds - 1) / rounds;
-        if (bytes > kPhaseLdsBytes || t_in > (int64_t)kPhasePF * 64 * nw) break;
-        nb = cand; threads = 64 * nw; tile_in = (int)t_in;
+            c.gi[u] = c.io[u * Q + Q - 1];
+            c.i_max = std::max(c.i_max, c.gi[u]);
+            max_back = std::max(max_back, c.gi[u] - c.io[u * Q]);
+        }
+        c.wlen = (taps + max_back + 7) & ~7;
+        // lane runs in the output area: a multiple of 4 floats whose quarter is odd keeps the 16-byte accesses of 64 lanes on distinct banks
+        c.ls = (L / 4) % 2 == 1 ? (int)L : (int)L + 4;
+        // lane blocks per tile: as many as LDS and the prefetch registers hold
+        for (int cand = 1; cand <= 64; ++cand) {
+            const int64_t t_in = c.wlen + (int64_t)cand * 64 * c.D + c.i_max + 1;
+            const int64_t bytes = 4 * (((t_in + 3) & ~(int64_t)3) + (int64_t)cand * 64 * c.ls);
+            const int tasks = cand * c.groups;
+            const int rounds = (tasks + 15) / 16;
+            const int nw = (tasks + rounds - 1) / rounds;
+            if (bytes > kPhaseLdsBytes || t_in > (int64_t)kPhasePF * 64 * nw) break;
+            c.nb = cand; c.threads = 64 * nw; c.tile_in = (int)t_in;
+            c.cost = (double)rounds * ((nw + 3) / 4) * c.wlen * Q / ((double)cand * 64 * L);
+        }
+        if (c.nb > 0 && (best.Q == 0 || c.cost < best.cost)) best = c;
     }
-    if (nb == 0) return MMFE_OK;
+    if (best.Q == 0) return MMFE_OK;
+    const int Q = best.Q, wlen = best.wlen;
+    std::vector<float> wt((size_t)best.groups * wlen * Q, 0.f);
+    for (int u = 0; u < best.groups; ++u)
+        for (int sidx = 0; sidx < wlen; ++sidx)
+            for (int q = 0; q < Q; ++q) {
+                const int t = sidx - (best.gi[u] - best.io[u * Q + q]);
+                if (t >= 0 && t < taps)
+                    wt[(((size_t)u * (wlen / 8) + sidx / 8) * Q + q) * 8 + sidx % 8] = bank[(size_t)best.ph[u * Q + q] * taps_padded + t];
+            }
     if ((rc = upload(&plan.d_tw_a, wt))) return rc;
-    if ((rc = upload(&plan.d_mel_start, gi))) return rc;
-    plan.rs_L = (int)L; plan.rs_D = (int)D; plan.rs_nb = nb; plan.rs_groups = groups; plan.rs_wlen = wlen;
-    plan.rs_tile_in = tile_in; plan.rs_ls = ls; plan.rs_threads = threads;
+    if ((rc = upload(&plan.d_mel_start, best.gi))) return rc;
+    plan.rs_q = Q; plan.rs_L = best.L; plan.rs_D = best.D; plan.rs_nb = best.nb; plan.rs_groups = best.groups; plan.rs_wlen = wlen;
+    plan.rs_tile_in = best.tile_in; plan.rs_ls = best.ls; plan.rs_threads = best.threads;
     return MMFE_OK;
 }
 
@@ -355,15 +430,23 @@ int resample_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
         a.gi = plan.d_mel_start;
         a.vec_out = (reinterpret_cast<uintptr_t>(out) % 16 == 0 && out_len % 4 == 0) ? 1 : 0;
         const size_t lds = 4 * ((size_t)((a.tile_in + 3) & ~3) + (size_t)a.nb * 64 * a.ls);
-        const void* fn = pcm ? reinterpret_cast<const void*>(&resample_phase_kernel<int16_t>) : reinterpret_cast<const void*>(&resample_phase_kernel<float>);
+        // whole four-sample pieces: rows on 4-sample boundaries of aligned memory, a multiple of 4 samples each, no per-row lengths
+        const bool vec = src.offsets == nullptr && src.row_len == nullptr && n_samples % 4 == 0 && n_samples >= 4 && src.stride % 4 == 0 &&
+                         reinterpret_cast<uintptr_t>(src.base) % (pcm ? 8 : 16) == 0;
+        typedef void (*phase_fn)(const ResamplePhaseArgs);
+        const phase_fn table[2][2][2] = {
+            {{&resample_phase_kernel<float, 4, false>, &resample_phase_kernel<float, 4, true>},
+             {&resample_phase_kernel<float, 5, false>, &resample_phase_kernel<float, 5, true>}},
+            {{&resample_phase_kernel<int16_t, 4, false>, &resample_phase_kernel<int16_t, 4, true>},
+             {&resample_phase_kernel<int16_t, 5, false>, &resample_phase_kernel<int16_t, 5, true>}}};
+        const phase_fn kfn = table[pcm ? 1 : 0][plan.rs_q == 5 ? 1 : 0][vec ? 1 : 0];
         int per_cu = 1, cus = 256;
-        const int rc = kernel_prepare(fn, plan.rs_threads, lds, &per_cu, &cus);
+        const int rc = kernel_prepare(reinterpret_cast<const void*>(kfn), plan.rs_threads, lds, &per_cu, &cus);
         if (rc) return rc;
         const int64_t n_tiles = n_rows * a.tiles_per_row;
         if (n_tiles >= ((int64_t)1 << 31) - 65536 || n_out + a.tile_out >= (int64_t)1 << 31) { set_error("RESAMPLE: batch too large for one launch"); return MMFE_EINVAL; }
         const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)cus * std::max(1, per_cu));
-        if (pcm) hipLaunchKernelGGL(resample_phase_kernel<int16_t>, dim3(grid), dim3(plan.rs_threads), lds, stream, a);
-        else hipLaunchKernelGGL(resample_phase_kernel<float>, dim3(grid), dim3(plan.rs_threads), lds, stream, a);
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(plan.rs_threads), lds, stream, a);
         MMFE_HIP_CHECK(hipGetLastError());
         return MMFE_OK;
     }

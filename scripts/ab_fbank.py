@@ -2,7 +2,7 @@
 """A/B timing of several builds of libmmfe.so on one benchmark configuration, in ONE process with
 interleaved rounds (separate processes add variance that looks like a kernel property).
 
-    python scripts/ab_fbank.py [--config vgg|logmel|har] [--batch N] [--rounds 6] [--launches 20] name=path.so[@VAR=VALUE,...] [name=path.so ...]
+    python scripts/ab_fbank.py [--config vgg|logmel|har|resample] [--batch N] [--rounds 6] [--launches 20] name=path.so[@VAR=VALUE,...] [name=path.so ...]
 
   vgg     VGGSound log-mel, 4096 clips of 160 000 samples (kernel fbank512)
   logmel  long-utterance log-mel, 1024 utterances of 480 000 samples (kernel rfft400 + clamp pass)
@@ -37,6 +37,9 @@ def build_plan(path, device, in_dtype=N.IN_F32, config="vgg"):
     if config == "har":
         from multi_modal_amd import har
         return har._stft_plan(device, 32, 28)
+    if config == "resample":
+        from multi_modal_amd import resample
+        return resample._plan(device, 160, 441, 0, in_dtype)
     kw = dict(vggsound._KW)
     plan = kaldi._fbank_plan(device, sample_frequency=kw["sample_frequency"], frame_length=25.0, frame_shift=kw["frame_shift"],
                              num_mel_bins=kw["num_mel_bins"], window_type=kw["window_type"], blackman_coeff=0.42,
@@ -48,7 +51,7 @@ def build_plan(path, device, in_dtype=N.IN_F32, config="vgg"):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", choices=("vgg", "logmel", "har"), default="vgg")
+    ap.add_argument("--config", choices=("vgg", "logmel", "har", "resample"), default="vgg")
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--launches", type=int, default=20)
@@ -63,6 +66,8 @@ def main():
         rows, n, oshape = args.batch or 4096, args.samples, (384, 128)
     elif args.config == "logmel":
         rows, n, oshape = args.batch or 1024, 480000, (80, 3000)
+    elif args.config == "resample":
+        rows, n, oshape = args.batch or 1024, 441000, (160000,)
     else:
         n = args.samples if args.samples != 160000 else 192          # --samples: window length (default 192)
         rows, oshape = 6 * (args.batch or 262144), (17, 1 + (n + 3) // 4)
