@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace mmfe {
@@ -200,6 +201,22 @@ __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const 
             pf[q] = __builtin_nontemporal_load(x + (g < 0 ? 0 : (g < n_row ? g : n_row - 1)));
         }
     };
+    // the same, one piece at a time (VEC): `next_begin` sets the row pointer and range of the tile, `next_piece(q)` requests piece q
+    const SMP* nx = nullptr;
+    int nlo = 0, nrow = 0;
+    auto next_begin = [&](unsigned tile) {
+        const unsigned t = tile < n_tiles ? tile : 0;                   // (beyond the batch: tile 0 is read and never staged)
+        const unsigned row = t / (unsigned)p.tiles_per_row;
+        const int m0 = (int)(t - row * (unsigned)p.tiles_per_row) * p.tile_out;
+        nlo = (m0 / p.up) * p.down - p.wlen;
+        nx = row_ptr_as<SMP>(p.src, row);
+        nrow = row_samples(p.src, row, p.n_in);
+    };
+    auto next_piece = [&](auto q_tag) {
+        constexpr int q = decltype(q_tag)::value;
+        const int g = nlo + 4 * ((int)threadIdx.x + q * (int)blockDim.x);
+        pv[VEC ? q : 0] = __builtin_nontemporal_load(reinterpret_cast<const piece_t*>(nx + (g < 0 ? 0 : (g + 4 <= nrow ? g : nrow - 4))));
+    };
     // ---- drain: lane run j holds outputs m0 + j * L .. + L - 1 of `row` ----
     auto drain = [&](unsigned row, int m0) {
         float* orow = p.out + (int64_t)row * p.out_stride;
@@ -224,8 +241,15 @@ __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const 
             }
         }
     };
+#ifdef MMFE_RS_STAMPS
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = 0, st_now = 0;
+#define RS_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory"); __builtin_amdgcn_sched_barrier(0); if ((i) >= 0) st_acc[(i)] += st_now - st_prev; st_prev = st_now; } while (0)
+#else
+#define RS_STAMP(i) do { } while (0)
+#endif
     fetch(blockIdx.x);
     for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        RS_STAMP(-1);
         const unsigned row = tile / (unsigned)p.tiles_per_row;
         const int m0 = (int)(tile - row * (unsigned)p.tiles_per_row) * p.tile_out;
         // ---- stage: registers -> LDS (the previous tile's readers passed the barrier that ended its multiply-adds; its drain
@@ -250,9 +274,21 @@ __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const 
                 }
             }
         }
+        RS_STAMP(0);      // stage
         lds_barrier();
-        fetch(tile + gridDim.x);                                        // in flight under the arithmetic below (requested after the
-                                                                        // first run instead: 3 % slower)
+        RS_STAMP(1);      // barrier after stage
+        // The next tile's samples, requested here all at once.  s_memtime stamps (-DMMFE_RS_STAMPS) show the later waves of a block
+        // sitting in the issue of these loads for up to 4 000 of a step's 24 000 cycles (16 waves x 9 loads pass the CU's 64 B/clk
+        // path to L1 one after the other).  -DMMFE_RS_FETCH_SPREAD=1 has each wave request ONE piece per chunk of its first run
+        // instead (VEC only): the waiting moves into the runs and the step takes as long (16-bit rows +0.6 %, float32 rows +5 %).
+#ifndef MMFE_RS_FETCH_SPREAD
+#define MMFE_RS_FETCH_SPREAD 0
+#endif
+        constexpr bool kSpread = VEC && MMFE_RS_FETCH_SPREAD;
+        bool fetched = !kSpread;
+        if (!kSpread) fetch(tile + gridDim.x);
+        else next_begin(tile + gridDim.x);
+        RS_STAMP(2);      // fetch issue
         // ---- runs: (lane block, group) pairs spread over the waves ----
         for (int task = wave; task < p.nb * p.groups; task += n_waves) {
             const int blk = task / p.groups;
@@ -271,7 +307,7 @@ __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const 
             // everything, and the other waves of the SIMD already fill the gaps)
             // (skipping, in the window's first and last chunks, the outputs that have no taps there - 13 % of the multiply-adds - measured
             // 5 to 23 % slower: the wave-uniform branches cost the loop its overlap of loads and arithmetic)
-            for (int c = 0; c < chunks; ++c) {
+            auto chunk = [&](int c) {
                 f32x8 wq[Q];
 #pragma unroll
                 for (int q = 0; q < Q; ++q) wq[q] = w[c * Q + q];
@@ -281,7 +317,21 @@ __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const 
 #pragma unroll
                     for (int q = 0; q < Q; ++q) acc[q] = fmaf(wq[q][e], xv, acc[q]);
                 }
+            };
+            int c = 0;
+            if (kSpread && !fetched) {                                  // the wave's first run of the tile: chunk q also requests piece q
+                auto step = [&](auto q_tag) {
+                    next_piece(q_tag);
+                    if (decltype(q_tag)::value < chunks) chunk(decltype(q_tag)::value);
+                };
+                step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+                step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+                step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+                static_assert(kPieces == 9, "one step per piece");
+                c = kPieces < chunks ? kPieces : chunks;
+                fetched = true;
             }
+            for (; c < chunks; ++c) chunk(c);
             float* so = s_o + (blk * 64 + lane) * p.ls + Q * u;
             if (Q == 4) {
                 *reinterpret_cast<f32x4*>(so) = f32x4{acc[0], acc[1], acc[2], acc[3]};
@@ -290,13 +340,21 @@ __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const 
                 for (int q = 0; q < Q; ++q) so[q] = acc[q];
             }
         }
+        if (!fetched) fetch(tile + gridDim.x);                          // (a wave without a run in this tile)
+        RS_STAMP(3);      // runs
         lds_barrier();
+        RS_STAMP(4);      // barrier after runs
         // (storing a tile's outputs one step later instead - after the next tile is staged and before its samples' successors are
         // requested, so that no stage ever waits behind stores - measured 6 % (16-bit input) to 16 % (float32) slower)
         drain(row, m0);
+        RS_STAMP(5);      // drain
         // (no barrier here: the next step's stage only writes s_x, whose readers passed the barrier above, and s_o is not written
         // again before the barrier that follows the stage)
     }
+#ifdef MMFE_RS_STAMPS
+    if (blockIdx.x == 3 && lane == 0 && (wave == 0 || wave == 9))
+        printf("wave %d, shader-clock cycles: stage %llu  barrier %llu  load issue %llu  runs %llu  barrier %llu  drain %llu\n", wave, st_acc[0], st_acc[1], st_acc[2], st_acc[3], st_acc[4], st_acc[5]);
+#endif
 }
 
 }  // namespace

@@ -6,6 +6,9 @@ __global__ void __launch_bounds__(256) probe(float* out, int iters) {
     float a[16];
     for (int i = 0; i < 16; ++i) a[i] = threadIdx.x * 0.001f + i;
     float m = 1.0001f + threadIdx.x * 1e-9f, c = 0.0001f;
+    const float sm = __builtin_amdgcn_readfirstlane(iters) * 1e-9f + 1.0f;
+    float sw[8];
+    for (int i = 0; i < 8; ++i) sw[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sm + i * 1e-6f)));
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -23,6 +26,8 @@ __global__ void __launch_bounds__(256) probe(float* out, int iters) {
                 if (OP == 9) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 15]));
                 if (OP == 10) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(*reinterpret_cast<double*>(&a[2 * (i & 7)])) : "v"(*reinterpret_cast<double*>(&m)));
                 if (OP == 11) asm volatile("v_log_f32 %0, %0" : "+v"(a[i]));
+                if (OP == 12) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "s"(sm), "v"(c));      // scalar-register multiplicand
+                if (OP == 13) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "s"(sw[i & 7]), "v"(c));  // eight different scalar registers in turn
             }
     }
     float s = 0;
@@ -48,6 +53,7 @@ int main() {
     run<0>("v_fma_f32", d); run<1>("v_add_f32", d); run<2>("v_mul_f32", d); run<3>("v_sub_f32", d);
     run<4>("v_cndmask_b32", d); run<5>("v_add_u32", d); run<6>("v_mov_dpp", d); run<7>("v_max_f32", d);
     run<8>("v_fmac_f32", d); run<9>("v_mov_b32", d); run<10>("v_fma_f64", d); run<11>("v_log_f32", d);
+    run<12>("v_fmac s,v", d); run<13>("v_fmac s[i],v", d);
     run<0>("v_fma_f32", d);
     return 0;
 }
