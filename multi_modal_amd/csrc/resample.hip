@@ -27,6 +27,7 @@
 #include "fft_regs.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <string>
 #include <type_traits>
@@ -357,6 +358,116 @@ __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const 
 #endif
 }
 
+// ---- the same for 16-bit PCM rows, two blocks per CU ------------------------------------------------------------------
+// With 113 KB of staged float32 samples per 64 lanes only one block of the kernel above fits a CU, and its SIMDs issue nothing
+// while it stages, requests loads or stores.  PCM rows can stay 16-bit in LDS (56 KB per tile) and a block can store its outputs
+// round by round (16 runs of Q outputs per lane: 21 KB instead of 41 KB): two blocks then share a CU.  The samples are converted
+// where they are read (one 2-byte LDS read and one v_cvt each) and the 1 / 32768 of the decode rides on the weights, which is
+// exact (a power-of-two scale commutes with every rounding of the multiply-adds): the outputs equal the other kernel's bit for
+// bit.  Measured gain: 4 % (0.637 against 0.663 ms per 1024 ten-second clips) - the runs are bound by instruction issue (every
+// instruction of any kind costs a SIMD about 2.5 cycles: a pure-arithmetic build scales with its instruction count), the 16
+// extra instructions per chunk of 40 multiply-adds (reads, converts) eat most of what the overlap returns.
+// Needs: whole four-sample pieces (VEC above), one lane block per tile, a whole number of rounds (groups % waves == 0).
+struct ResamplePhase16Args {
+    ResamplePhaseArgs a;       // wt: the weights scaled by 1 / 32768;  ls: floats between the lane runs of one ROUND in LDS
+    int rounds;                // groups / waves
+    int round_out;             // outputs of a lane per round: waves * Q
+};
+
+template <int Q>
+__global__ void __launch_bounds__(kMaxPhaseThreads, 8) resample_phase16_kernel(const ResamplePhase16Args pp) {
+    const ResamplePhaseArgs& p = pp.a;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int16_t* s_x = reinterpret_cast<int16_t*>(smem);                                           // tile_in (rounded up to 8)
+    float* s_o = reinterpret_cast<float*>(smem + 2 * (size_t)((p.tile_in + 7) & ~7));          // 64 * ls
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_waves = blockDim.x >> 6;
+    const unsigned n_tiles = (unsigned)p.n_rows * (unsigned)p.tiles_per_row;
+    const int chunks = p.wlen >> 3;
+    constexpr int kPieces = kPhasePF / 4;
+    u32x2 pv[kPieces];
+    auto fetch = [&](unsigned tile) {
+        if (tile >= n_tiles) return;
+        const unsigned row = tile / (unsigned)p.tiles_per_row;
+        const int m0 = (int)(tile - row * (unsigned)p.tiles_per_row) * p.tile_out;
+        const int lo = (m0 / p.up) * p.down - p.wlen;
+        const int16_t* x = row_ptr_as<int16_t>(p.src, row);
+#pragma unroll
+        for (int q = 0; q < kPieces; ++q) {
+            const int g = lo + 4 * ((int)threadIdx.x + q * (int)blockDim.x);
+            pv[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(x + (g < 0 ? 0 : (g + 4 <= p.n_in ? g : p.n_in - 4))));
+        }
+    };
+    fetch(blockIdx.x);
+    for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const unsigned row = tile / (unsigned)p.tiles_per_row;
+        const int m0 = (int)(tile - row * (unsigned)p.tiles_per_row) * p.tile_out;
+        const int lo = (m0 / p.up) * p.down - p.wlen;
+        // ---- stage: the pieces as they are, zeros outside the row (the previous tile's readers passed the barrier behind its last round) ----
+#pragma unroll
+        for (int q = 0; q < kPieces; ++q) {
+            const int k = 4 * ((int)threadIdx.x + q * (int)blockDim.x);
+            const int g = lo + k;
+            if (k < p.tile_in) *reinterpret_cast<u32x2*>(s_x + k) = (g >= 0 && g + 4 <= p.n_in) ? pv[q] : u32x2{0u, 0u};
+        }
+        lds_barrier();
+        fetch(tile + gridDim.x);
+        float* orow = p.out + (int64_t)row * p.out_stride + m0;
+        const bool whole = p.vec_out && m0 + p.tile_out <= p.n_out;
+        for (int r = 0; r < pp.rounds; ++r) {
+            const int u = r * n_waves + wave;
+            const int16_t* xl = s_x + p.wlen + lane * p.D + ((const_int*)p.gi)[u];
+            typedef __attribute__((address_space(3))) const int16_t lds_i16;
+            lds_i16* xl3 = (lds_i16*)xl;
+            const_f32x8* w = ((const_f32x8*)p.wt) + (int64_t)u * chunks * Q;
+            float acc[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) acc[q] = 0.f;
+            for (int c = 0; c < chunks; ++c) {
+                f32x8 wq[Q];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) wq[q] = w[c * Q + q];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    // one 2-byte LDS read per sample (this file is compiled with the IR load/store vectoriser off, see the Makefile:
+                    // left on, it fetches the chunk's 8 samples with one ds_read_b128 at a 2-byte aligned address, which the LDS
+                    // serves in 73 cycles per wave)
+                    const float xv = (float)xl3[-(c * 8 + e)];
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) acc[q] = fmaf(wq[q][e], xv, acc[q]);
+                }
+            }
+            float* so = s_o + lane * p.ls + Q * wave;
+            if (Q == 4) {
+                *reinterpret_cast<f32x4*>(so) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+            } else {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) so[q] = acc[q];
+            }
+            lds_barrier();
+            // ---- the round's outputs: lane run j holds outputs m0 + j * L + r * round_out .. + round_out - 1 ----
+            if (whole) {
+                const int r4 = pp.round_out >> 2;                   // 16-byte pieces per lane run
+                for (int i = threadIdx.x; i < 64 * r4; i += blockDim.x) {
+                    const int j = i / r4, k = i - j * r4;
+                    __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(s_o + j * p.ls + 4 * k),
+                                                reinterpret_cast<f32x4*>(orow + (int64_t)j * p.L + r * pp.round_out) + k);
+                }
+            } else {
+                for (int i = threadIdx.x; i < 64 * pp.round_out; i += blockDim.x) {
+                    const int j = i / pp.round_out, k = i - j * pp.round_out;
+                    const int64_t m = (int64_t)j * p.L + r * pp.round_out + k;
+                    if (m0 + m < p.n_out) __builtin_nontemporal_store(s_o[j * p.ls + k], orow + m);
+                }
+            }
+            // the output area is written again at the end of the next round's runs; a round that is followed by the stage of the
+            // next tile needs no barrier here: the barrier behind that stage stands between these reads and those writes
+            if (r + 1 < pp.rounds) lds_barrier();
+        }
+    }
+}
+
 }  // namespace
 
 int resample_prepare(Plan& plan) {
@@ -455,6 +566,54 @@ int resample_prepare(Plan& plan) {
     if ((rc = upload(&plan.d_mel_start, best.gi))) return rc;
     plan.rs_q = Q; plan.rs_L = best.L; plan.rs_D = best.D; plan.rs_nb = best.nb; plan.rs_groups = best.groups; plan.rs_wlen = wlen;
     plan.rs_tile_in = best.tile_in; plan.rs_ls = best.ls; plan.rs_threads = best.threads;
+
+    // ---- 16-bit rows: the two-blocks-per-CU form (samples stay 16-bit in LDS, outputs leave round by round) ----
+    plan.rs16_threads = 0;
+    if (s.in_dtype != MMFE_IN_S16 || (force != nullptr && std::string(force) == "wide")) return MMFE_OK;   // "wide": the one-block form for PCM too
+    for (int Q16 = 5; Q16 >= 4 && plan.rs16_threads == 0; --Q16) {
+        if (force_q != nullptr && std::atoi(force_q) != Q16) continue;
+        const int64_t L = (int64_t)up * ((Q16 + up - 1) / up);
+        if (L % Q16 != 0 || L % 4 != 0 || L > 4096) continue;
+        const int groups = (int)(L / Q16);
+        const int D = (int)(L * down / up);
+        std::vector<int32_t> gi(groups);
+        std::vector<int> io(groups * Q16), ph(groups * Q16);
+        int max_back = 0, i_max = 0;
+        for (int u = 0; u < groups; ++u) {
+            for (int q = 0; q < Q16; ++q) {
+                const int64_t t = (int64_t)(Q16 * u + q + pre) * down;
+                io[u * Q16 + q] = (int)(t / up);
+                ph[u * Q16 + q] = (int)(t % up);
+            }
+            gi[u] = io[u * Q16 + Q16 - 1];
+            i_max = std::max(i_max, gi[u]);
+            max_back = std::max(max_back, gi[u] - io[u * Q16]);
+        }
+        const int wlen16 = (taps + max_back + 7) & ~7;
+        const int64_t t_in = wlen16 + (int64_t)64 * D + i_max + 1;
+        for (int nw = 16; nw >= 8; --nw) {          // the most waves that divide the groups into whole rounds
+            if (groups % nw != 0 || (nw * Q16) % 4 != 0) continue;
+            if (groups / nw > 2) continue;              // more rounds per tile mean more barriers around the rounds' stores than the second block returns
+            const int round_out = nw * Q16;
+            const int ls16 = (round_out / 4) % 2 == 1 ? round_out : round_out + 4;
+            const int64_t bytes = 2 * ((t_in + 7) & ~(int64_t)7) + (int64_t)64 * ls16 * 4;
+            if (bytes > kPhaseLdsBytes / 2 || t_in > (int64_t)kPhasePF * 64 * nw) continue;
+            std::vector<float> wt16((size_t)groups * wlen16 * Q16, 0.f);
+            for (int u = 0; u < groups; ++u)
+                for (int sidx = 0; sidx < wlen16; ++sidx)
+                    for (int q = 0; q < Q16; ++q) {
+                        const int t = sidx - (gi[u] - io[u * Q16 + q]);
+                        if (t >= 0 && t < taps)
+                            wt16[(((size_t)u * (wlen16 / 8) + sidx / 8) * Q16 + q) * 8 + sidx % 8] =
+                                bank[(size_t)ph[u * Q16 + q] * taps_padded + t] * (1.0f / 32768.0f);
+                    }
+            if ((rc = upload(&plan.d_tw_b, wt16))) return rc;
+            if ((rc = upload(&plan.d_mel_niter, gi))) return rc;
+            plan.rs16_q = Q16; plan.rs16_L = (int)L; plan.rs16_D = D; plan.rs16_groups = groups; plan.rs16_wlen = wlen16;
+            plan.rs16_tile_in = (int)t_in; plan.rs16_ls = ls16; plan.rs16_threads = 64 * nw; plan.rs16_round_out = round_out;
+            break;
+        }
+    }
     return MMFE_OK;
 }
 
@@ -471,6 +630,40 @@ int resample_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
     if (n_samples >= ((int64_t)1 << 31) / 2 || n_rows >= (int64_t)1 << 31) { set_error("RESAMPLE: row too long for one launch"); return MMFE_EINVAL; }
     const int up = s.n_fft, down = s.hop, n_taps = s.win_len;
     const bool pcm = s.in_dtype == MMFE_IN_S16;
+    if (plan.rs16_threads > 0 && src.offsets == nullptr && src.row_len == nullptr && n_samples % 4 == 0 && n_samples >= 4 && src.stride % 4 == 0 &&
+        reinterpret_cast<uintptr_t>(src.base) % 8 == 0) {
+        ResamplePhase16Args b{};
+        ResamplePhaseArgs& a = b.a;
+        a.src = src;
+        a.out = out;
+        a.n_rows = (int)n_rows;
+        a.n_in = (int)n_samples;
+        a.n_out = n_out;
+        a.out_stride = out_len;
+        a.up = up; a.down = down;
+        a.L = plan.rs16_L; a.D = plan.rs16_D; a.nb = 1; a.groups = plan.rs16_groups; a.wlen = plan.rs16_wlen;
+        a.tile_in = plan.rs16_tile_in; a.ls = plan.rs16_ls;
+        a.tile_out = 64 * a.L;
+        a.tiles_per_row = (int)((n_out + a.tile_out - 1) / a.tile_out);
+        a.wt = plan.d_tw_b;
+        a.gi = plan.d_mel_niter;
+        a.vec_out = (reinterpret_cast<uintptr_t>(out) % 16 == 0 && out_len % 4 == 0) ? 1 : 0;
+        b.rounds = a.groups / (plan.rs16_threads / 64);
+        b.round_out = plan.rs16_round_out;
+        const size_t lds = 2 * (size_t)((a.tile_in + 7) & ~7) + (size_t)64 * a.ls * 4;
+        typedef void (*phase16_fn)(const ResamplePhase16Args);
+        const phase16_fn kfn = plan.rs16_q == 5 ? &resample_phase16_kernel<5> : &resample_phase16_kernel<4>;
+        int per_cu = 1, cus = 256;
+        const int rc = kernel_prepare(reinterpret_cast<const void*>(kfn), plan.rs16_threads, lds, &per_cu, &cus);
+        if (rc) return rc;
+        const int64_t n_tiles = n_rows * a.tiles_per_row;
+        if (n_tiles >= ((int64_t)1 << 31) - 65536 || n_out + a.tile_out >= (int64_t)1 << 31) { set_error("RESAMPLE: batch too large for one launch"); return MMFE_EINVAL; }
+        const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)cus * std::max(1, per_cu));
+        if (std::getenv("MMFE_DEBUG_LAUNCH")) std::fprintf(stderr, "resample_phase16: Q %d threads %d lds %zu blocks/CU %d grid %d rounds %d round_out %d ls %d tile_in %d\n", plan.rs16_q, plan.rs16_threads, lds, per_cu, grid, b.rounds, b.round_out, a.ls, a.tile_in);
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(plan.rs16_threads), lds, stream, b);
+        MMFE_HIP_CHECK(hipGetLastError());
+        return MMFE_OK;
+    }
     if (plan.rs_L > 0) {
         ResamplePhaseArgs a{};
         a.src = src;
