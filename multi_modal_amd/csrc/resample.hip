@@ -659,7 +659,6 @@ int resample_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
         const int64_t n_tiles = n_rows * a.tiles_per_row;
         if (n_tiles >= ((int64_t)1 << 31) - 65536 || n_out + a.tile_out >= (int64_t)1 << 31) { set_error("RESAMPLE: batch too large for one launch"); return MMFE_EINVAL; }
         const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)cus * std::max(1, per_cu));
-        if (std::getenv("MMFE_DEBUG_LAUNCH")) std::fprintf(stderr, "resample_phase16: Q %d threads %d lds %zu blocks/CU %d grid %d rounds %d round_out %d ls %d tile_in %d\n", plan.rs16_q, plan.rs16_threads, lds, per_cu, grid, b.rounds, b.round_out, a.ls, a.tile_in);
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(plan.rs16_threads), lds, stream, b);
         MMFE_HIP_CHECK(hipGetLastError());
         return MMFE_OK;
