@@ -1231,6 +1231,31 @@ def test_resample_both_kernels_agree(mm, O, monkeypatch):
     assert np.abs(fast - slow).max() <= 1e-6
 
 
+@pytest.mark.parametrize("rows,n", [(3, 441000), (5, 100004), (2, 30000), (70, 61740), (1, 8)])
+def test_resample_pcm_two_block_form_is_bit_identical(mm, O, monkeypatch, rows, n):
+    """16-bit rows of aligned batches take the form that keeps the samples 16-bit in LDS and runs two blocks per CU;
+    MMFE_RESAMPLE_FORM=wide (read at plan creation) keeps them on the one-block form.  The 1 / 32768 of the decode moves from the
+    samples to the weights, a power-of-two scale: the outputs must be the same bits.  Shapes: whole tiles plus a partial last tile,
+    rows shorter than one tile, many rows per block, a row of 8 samples; full-scale samples included; the batch is followed by
+    other data (a read past its end would show)."""
+    rng = np.random.default_rng(rows * 1000 + n)
+    pcm = rng.integers(-32768, 32768, size=(rows, n), dtype=np.int16)
+    pcm[0, :4] = [32767, -32768, 32767, -32768]
+    guard = torch.full((rows * n + 64,), 12345, dtype=torch.int16, device="cuda")
+    x = guard[: rows * n].view(rows, n)
+    x.copy_(torch.from_numpy(pcm))
+    mm.plans.clear_plans()
+    two = mm.resample_batch(x, 44100, 16000)
+    mm.plans.clear_plans()
+    monkeypatch.setenv("MMFE_RESAMPLE_FORM", "wide")
+    one = mm.resample_batch(x, 44100, 16000)
+    monkeypatch.delenv("MMFE_RESAMPLE_FORM")
+    mm.plans.clear_plans()
+    assert torch.equal(two, one)
+    ref = O.resample_poly(pcm.astype(np.float32) / 32768.0, 44100, 16000)
+    assert two.shape == ref.shape and np.abs(two.cpu().numpy() - ref).max() <= 4e-6
+
+
 def test_device_prefetcher_overlapped_batches(mm, O):
     """DataLoader-shaped batches (waveforms + labels) through the pinned-buffer prefetcher with the fused transform: every batch
     equals the direct call on the same clips, in order, for several depths, batch counts around the pipeline depth, a ragged last
