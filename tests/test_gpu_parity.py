@@ -1231,12 +1231,13 @@ def test_resample_both_kernels_agree(mm, O, monkeypatch):
     assert np.abs(fast - slow).max() <= 1e-6
 
 
-@pytest.mark.parametrize("rows,n", [(3, 441000), (5, 100004), (2, 30000), (70, 61740), (1, 8)])
+@pytest.mark.parametrize("rows,n", [(3, 441000), (5, 100004), (2, 30000), (70, 61740), (1, 8), (2, 50002), (3, 50001)])
 def test_resample_pcm_two_block_form_is_bit_identical(mm, O, monkeypatch, rows, n):
     """16-bit rows of aligned batches take the form that keeps the samples 16-bit in LDS and runs two blocks per CU;
     MMFE_RESAMPLE_FORM=wide (read at plan creation) keeps them on the one-block form.  The 1 / 32768 of the decode moves from the
     samples to the weights, a power-of-two scale: the outputs must be the same bits.  Shapes: whole tiles plus a partial last tile,
-    rows shorter than one tile, many rows per block, a row of 8 samples; full-scale samples included; the batch is followed by
+    rows shorter than one tile, many rows per block, a row of 8 samples, row lengths that are not a multiple of 4 (both settings
+    then run the sample-by-sample staging); full-scale samples included; the batch is followed by
     other data (a read past its end would show)."""
     rng = np.random.default_rng(rows * 1000 + n)
     pcm = rng.integers(-32768, 32768, size=(rows, n), dtype=np.int16)
