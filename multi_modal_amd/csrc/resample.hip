@@ -387,12 +387,25 @@ __global__ void __launch_bounds__(kMaxPhaseThreads, 8) resample_phase16_kernel(c
     const int chunks = p.wlen >> 3;
     constexpr int kPieces = kPhasePF / 4;
     u32x2 pv[kPieces];
+    // -DMMFE_RS16_INTERIOR=1: tiles whose staged range lies inside the row (all but a row's first and last) take paths without
+    // per-piece tests.  Fewer instructions, but at this kernel's 64-register cap the second code path costs more scalar-register
+    // spills than the tests did: measured 1.3 % slower, so it is off.
+#ifndef MMFE_RS16_INTERIOR
+#define MMFE_RS16_INTERIOR 0
+#endif
+    const int span = 4 * kPieces * (int)blockDim.x;                  // samples the block's loads cover
     auto fetch = [&](unsigned tile) {
         if (tile >= n_tiles) return;
         const unsigned row = tile / (unsigned)p.tiles_per_row;
         const int m0 = (int)(tile - row * (unsigned)p.tiles_per_row) * p.tile_out;
         const int lo = (m0 / p.up) * p.down - p.wlen;
         const int16_t* x = row_ptr_as<int16_t>(p.src, row);
+        if (MMFE_RS16_INTERIOR && lo >= 0 && lo + span <= p.n_in) {   // block-uniform
+            const u32x2* xp = reinterpret_cast<const u32x2*>(x + lo) + threadIdx.x;
+#pragma unroll
+            for (int q = 0; q < kPieces; ++q) pv[q] = __builtin_nontemporal_load(xp + q * (int)blockDim.x);
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < kPieces; ++q) {
             const int g = lo + 4 * ((int)threadIdx.x + q * (int)blockDim.x);
@@ -405,11 +418,19 @@ __global__ void __launch_bounds__(kMaxPhaseThreads, 8) resample_phase16_kernel(c
         const int m0 = (int)(tile - row * (unsigned)p.tiles_per_row) * p.tile_out;
         const int lo = (m0 / p.up) * p.down - p.wlen;
         // ---- stage: the pieces as they are, zeros outside the row (the previous tile's readers passed the barrier behind its last round) ----
+        if (MMFE_RS16_INTERIOR && lo >= 0 && lo + span <= p.n_in) {
 #pragma unroll
-        for (int q = 0; q < kPieces; ++q) {
-            const int k = 4 * ((int)threadIdx.x + q * (int)blockDim.x);
-            const int g = lo + k;
-            if (k < p.tile_in) *reinterpret_cast<u32x2*>(s_x + k) = (g >= 0 && g + 4 <= p.n_in) ? pv[q] : u32x2{0u, 0u};
+            for (int q = 0; q < kPieces; ++q) {
+                const int k = 4 * ((int)threadIdx.x + q * (int)blockDim.x);
+                if (k < p.tile_in) *reinterpret_cast<u32x2*>(s_x + k) = pv[q];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < kPieces; ++q) {
+                const int k = 4 * ((int)threadIdx.x + q * (int)blockDim.x);
+                const int g = lo + k;
+                if (k < p.tile_in) *reinterpret_cast<u32x2*>(s_x + k) = (g >= 0 && g + 4 <= p.n_in) ? pv[q] : u32x2{0u, 0u};
+            }
         }
         lds_barrier();
         fetch(tile + gridDim.x);
