@@ -11,6 +11,8 @@ interleaved rounds (separate processes add variance that looks like a kernel pro
 Every build gets its own plan; round r times `launches` launches of every build in turn with HIP events.
 Prints per build: median / min of the per-launch times, the median of the per-round medians, and the maximum
 difference of its output from the first build's (a variant that changes the arithmetic shows up here).
+Variant libraries live under build/, which .gpurunignore lists (they are not part of the product): take the line out for an A/B run
+on the GPU box.
 """
 import argparse
 import os
