@@ -27,6 +27,7 @@
 #include "log_affine.h"
 
 #include <algorithm>
+#include <functional>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -745,6 +746,39 @@ int rfft400_prepare(Plan& plan) {
     std::vector<int> boff(s.n_mel + 1, 0);
     for (int m = 0; m < s.n_mel; ++m) boff[m + 1] = boff[m] + plan.band_len[m];
 
+    // Bank conflicts of the matrix-pipe operand reads.  Lane (block, j) of a stream reads bin ks + step of frame 4g + j; the 8 frames
+    // of an octet sit on 8 different residues of bank / 8 (kPS = 24 mod 64), so two filter blocks of a stream collide - all their
+    // lanes, on every step - exactly when their first bins agree mod 8.  A run may start up to 7 bins early (zero weights, the
+    // guard in front of bin 0 covers it) as long as it still ends within the stream's steps: the shifts below use that slack to
+    // give the filter blocks of a stream distinct residues where possible.  (Split streams are left as they are.)
+    std::vector<int> early(nfb, 0);
+    {
+        const char* e = std::getenv("MMFE_R400_DECONFLICT");      // tuning knob, read once per plan: 0 keeps every run at its first bin
+        const bool enabled = e == nullptr || std::atoi(e) != 0;
+        for (int st = 0; enabled && st < n_streams; ++st) {
+            if (split && st == n_streams - 1) continue;
+            std::vector<int> fbs;
+            for (int u = 16 * st; u < std::min(units, 16 * st + 16); u += 2) fbs.push_back(u >> 1);
+            const int n = (int)fbs.size();
+            std::sort(fbs.begin(), fbs.end(), [&](int a, int b) { return shape.s[st] - run[a] < shape.s[st] - run[b]; });   // least slack first
+            std::vector<int> pickd(n, 0), best;
+            int best_cost = 1 << 30;
+            // depth-first over the shifts: cost = filter blocks that share a residue with an earlier one, then the total shift
+            std::function<void(int, unsigned, int, int)> go = [&](int i, unsigned used, int clashes, int total) {
+                if (clashes * 1000 + total >= best_cost) return;
+                if (i == n) { best_cost = clashes * 1000 + total; best = pickd; return; }
+                const int fb = fbs[i];
+                const int slack = std::max(0, std::min(7, shape.s[st] - std::max(run[fb], 1)));
+                for (int d = 0; d <= slack; ++d) {
+                    const int r = ((kmin[fb] - d) % 8 + 8) % 8;
+                    pickd[i] = d;
+                    go(i + 1, used | (1u << r), clashes + ((used >> r) & 1u ? 1 : 0), total + d);
+                }
+            };
+            go(0, 0u, 0, 0);
+            for (int i = 0; i < n; ++i) early[fbs[i]] = best.empty() ? 0 : best[i];
+        }
+    }
     std::vector<int32_t> poff(kStreams * 64, kPGuard), dst(kStreams * 64, -1);
     std::vector<float> w((size_t)std::max(step_off[kStreams], 1) * 64, 0.f);
     for (int st = 0; st < n_streams; ++st) {
@@ -755,7 +789,7 @@ int rfft400_prepare(Plan& plan) {
             if (u >= units) continue;
             const int fb = u >> 1, g = u & 1;
             // a split stream walks [kmin, kmin + S) in blocks 0..7 and [kmin + S, kmin + 2S) in blocks 8..15
-            const int ks = kmin[fb] + part * shape.s[st];
+            const int ks = kmin[fb] - early[fb] + part * shape.s[st];
             for (int j = 0; j < 4; ++j) {
                 const int lane = 4 * blk + j;
                 poff[st * 64 + lane] = (4 * g + j) * kPS + kPGuard + ks;      // operand A: frame 4g+j of the octet
