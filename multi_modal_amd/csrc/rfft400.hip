@@ -750,29 +750,35 @@ int rfft400_prepare(Plan& plan) {
     // of an octet sit on 8 different residues of bank / 8 (kPS = 24 mod 64), so two filter blocks of a stream collide - all their
     // lanes, on every step - exactly when their first bins agree mod 8.  A run may start up to 7 bins early (zero weights, the
     // guard in front of bin 0 covers it) as long as it still ends within the stream's steps: the shifts below use that slack to
-    // give the filter blocks of a stream distinct residues where possible.  (Split streams are left as they are.)
+    // give the filter blocks of a stream distinct residues where possible.
     std::vector<int> early(nfb, 0);
     {
         const char* e = std::getenv("MMFE_R400_DECONFLICT");      // tuning knob, read once per plan: 0 keeps every run at its first bin
         const bool enabled = e == nullptr || std::atoi(e) != 0;
         for (int st = 0; enabled && st < n_streams; ++st) {
-            if (split && st == n_streams - 1) continue;
+            // a split stream walks each run in two halves S bins apart: its filter blocks hold two residues each
+            const bool split_here = split && st == n_streams - 1;
+            const int S = shape.s[st];
             std::vector<int> fbs;
-            for (int u = 16 * st; u < std::min(units, 16 * st + 16); u += 2) fbs.push_back(u >> 1);
+            for (int u = 16 * st; u < std::min(units, 16 * st + (split_here ? 8 : 16)); u += 2) fbs.push_back(u >> 1);
             const int n = (int)fbs.size();
-            std::sort(fbs.begin(), fbs.end(), [&](int a, int b) { return shape.s[st] - run[a] < shape.s[st] - run[b]; });   // least slack first
+            auto slack_of = [&](int fb) { return std::max(0, std::min(7, (split_here ? 2 * S : S) - std::max(run[fb], 1))); };
+            std::sort(fbs.begin(), fbs.end(), [&](int a, int b) { return slack_of(a) < slack_of(b); });   // least slack first
             std::vector<int> pickd(n, 0), best;
             int best_cost = 1 << 30;
-            // depth-first over the shifts: cost = filter blocks that share a residue with an earlier one, then the total shift
+            // depth-first over the shifts: cost = residues shared with an earlier filter block, then the total shift
             std::function<void(int, unsigned, int, int)> go = [&](int i, unsigned used, int clashes, int total) {
                 if (clashes * 1000 + total >= best_cost) return;
                 if (i == n) { best_cost = clashes * 1000 + total; best = pickd; return; }
                 const int fb = fbs[i];
-                const int slack = std::max(0, std::min(7, shape.s[st] - std::max(run[fb], 1)));
-                for (int d = 0; d <= slack; ++d) {
-                    const int r = ((kmin[fb] - d) % 8 + 8) % 8;
+                for (int d = 0; d <= slack_of(fb); ++d) {
+                    const int r0 = ((kmin[fb] - d) % 8 + 8) % 8, r1 = ((kmin[fb] - d + S) % 8 + 8) % 8;
+                    unsigned mine = 1u << r0;
+                    int c = (used >> r0) & 1u ? 1 : 0;
+                    if (split_here && r1 != r0) { c += (used >> r1) & 1u ? 1 : 0; mine |= 1u << r1; }
+                    else if (split_here) c += 1;
                     pickd[i] = d;
-                    go(i + 1, used | (1u << r), clashes + ((used >> r) & 1u ? 1 : 0), total + d);
+                    go(i + 1, used | mine, clashes + c, total + d);
                 }
             };
             go(0, 0u, 0, 0);
