@@ -217,7 +217,7 @@ constexpr int kWsPrefetch = 6;   // float4 registers per mover lane for the samp
 // LDS holds two input buffers and two output images.  In step t a block's compute waves work on its t-th group
 // (input buffer t & 1 -> image t & 1) while its mover waves store image (t - 1) & 1, drop the samples of group t + 1
 // (requested one step earlier) into input buffer (t + 1) & 1 and request those of group t + 2; one barrier ends the step.
-template <bool NT, bool MAGNITUDE>
+template <bool NT, bool MAGNITUDE, bool SPLIT /* n_samples % 4 != 0: a 16-byte piece may straddle two rows */>
 __global__ void __launch_bounds__(kMaxThreads) stft32_ws_kernel(const StftArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef float vf4 __attribute__((ext_vector_type(4)));
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(kMaxThreads) stft32_ws_kernel(const StftArgs p
     const int n_compute = blockDim.x - 64 * p.mover_waves;           // threads that compute
     const int n_mover = 64 * p.mover_waves;
     const bool mover = (int)threadIdx.x >= n_compute;
-    const int ml = (int)threadIdx.x - n_compute;                     // mover lane index
+    int ml = (int)threadIdx.x - n_compute;                           // mover lane index
     const float* gin = static_cast<const float*>(p.src.base);
 
     for (int i = threadIdx.x; i < 2 * R * (p.row_lds - T); i += blockDim.x) {   // zero margins of both input buffers: never overwritten
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(kMaxThreads) stft32_ws_kernel(const StftArgs p
     // A group's samples are one contiguous run of rows * T floats that starts 16-byte aligned (R is a multiple of 4), whatever T
     // is; lanes take whole 16-byte pieces of the run.  With T % 4 != 0 a piece may straddle two rows, and the batch's last piece
     // may be partial: that one is read float by float when it is staged, so that nothing is read beyond the batch.
-    const bool rows_split_pieces = (T & 3) != 0;
+    constexpr bool rows_split_pieces = SPLIT;
     vf4 pf[kWsPrefetch];
     auto fetch = [&](int grp) {                                      // movers: request group grp's samples
         const int row0 = grp * R;
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(kMaxThreads) stft32_ws_kernel(const StftArgs p
         for (int q = 0; q < kWsPrefetch; ++q) {
             const int e = 4 * (ml + q * n_mover);
             if (e >= n_el) continue;
-            if (!rows_split_pieces) {
+            if constexpr (!rows_split_pieces) {
                 const unsigned r = __umulhi((unsigned)e, p.inv_samples);
                 *reinterpret_cast<vf4*>(s_in + r * (unsigned)p.row_lds + 16 + ((unsigned)e - r * (unsigned)T)) = pf[q];
             } else {
@@ -309,6 +309,10 @@ __global__ void __launch_bounds__(kMaxThreads) stft32_ws_kernel(const StftArgs p
                 }
             }
         } else {
+            // A mover lane's piece indices, LDS rows and offsets are the same in every step.  Left visible, the optimiser keeps them
+            // all in registers across the loop (a dozen values per lane, spilled to scratch at this block size); recomputed per step
+            // they cost one multiply-high per piece.
+            asm volatile("" : "+v"(ml));
             if (t > 0) {                                              // store the previous group's image
                 const int prev = grp - (int)gridDim.x;
                 const int rows = min(R, p.n_rows - prev * R);
@@ -405,10 +409,12 @@ int stft32_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_
                 a.vec_in = a.vec_out = 1;
                 const int threads = 64 * (compute + movers);
                 const size_t lds = (size_t)(2 * r_ws * per_row_bytes);
-                const bool nt = plan.tune_nt != 0, mag = s.power == 1;
+                const bool nt = plan.tune_nt != 0, mag = s.power == 1, split = n_samples % 4 != 0;
                 typedef void (*ws_fn)(const StftArgs);
-                const ws_fn kfn = nt ? (mag ? &stft32_ws_kernel<true, true> : &stft32_ws_kernel<true, false>)
-                                     : (mag ? &stft32_ws_kernel<false, true> : &stft32_ws_kernel<false, false>);
+                const ws_fn kfn = split ? (nt ? (mag ? &stft32_ws_kernel<true, true, true> : &stft32_ws_kernel<true, false, true>)
+                                              : (mag ? &stft32_ws_kernel<false, true, true> : &stft32_ws_kernel<false, false, true>))
+                                        : (nt ? (mag ? &stft32_ws_kernel<true, true, false> : &stft32_ws_kernel<true, false, false>)
+                                              : (mag ? &stft32_ws_kernel<false, true, false> : &stft32_ws_kernel<false, false, false>));
                 const int rc = kernel_prepare(reinterpret_cast<const void*>(kfn), threads, lds, &blocks_per_cu, &cus);
                 if (rc) return rc;
                 const int64_t groups = (n_rows + r_ws - 1) / r_ws;

@@ -87,21 +87,31 @@ def spec_to_tensor(spec) -> torch.Tensor:
     return (t.to(torch.float32).unsqueeze(0) / 255 - 0.0) / 1.0
 
 
+def sound_slice_bounds_batch(start_frame, idx, fps_spec, n_total, resampling_rate: int = RESAMPLING_RATE) -> np.ndarray:
+    """The [left, right) sample ranges _extract_sound_feature cuts (epic_kitchen.py:130-152) for a whole batch at once:
+    array arguments of equal length (or scalars) -> (B, 2) int64.  +-0.639 s around (start_frame + idx) / fps, rounded
+    half-to-even like Python's round(); before the first / beyond the last sample the first / last round(1.279 * sr)
+    samples are taken instead (all of a shorter recording).  float64 throughout, like the Python scalars of the reference."""
+    frame = np.asarray(start_frame, dtype=np.int64) + np.asarray(idx, dtype=np.int64)
+    centre = frame.astype(np.float64) / np.asarray(fps_spec, dtype=np.float64)
+    n_total = np.broadcast_to(np.asarray(n_total, dtype=np.int64), centre.shape)
+    sr = float(resampling_rate)
+    left_sec, right_sec = centre - HALF_SPAN_SEC, centre + HALF_SPAN_SEC
+    edge = int(round(resampling_rate * EDGE_SEC))
+    at_start = left_sec < 0
+    at_end = ~at_start & (right_sec > n_total / sr)
+    left = np.rint(left_sec * resampling_rate).astype(np.int64)
+    right = np.rint(right_sec * resampling_rate).astype(np.int64)
+    left = np.where(at_start, 0, np.where(at_end, np.maximum(n_total - edge, 0), left))
+    right = np.where(at_start, np.minimum(edge, n_total), np.where(at_end, n_total, right))
+    return np.stack([left, right], axis=-1)
+
+
 def sound_slice_bounds(start_frame: int, idx: int, fps_spec: float, n_total: int,
                        resampling_rate: int = RESAMPLING_RATE) -> Tuple[int, int]:
-    """[left, right) sample range _extract_sound_feature cuts from a recording of n_total samples
-    (epic_kitchen.py:130-152): +-0.639 s around the frame's time stamp, clamped to the first / last
-    round(1.279 * sr) samples at the edges."""
-    centre_sec = (start_frame + idx) / fps_spec
-    left_sec = centre_sec - HALF_SPAN_SEC
-    right_sec = centre_sec + HALF_SPAN_SEC
-    duration = n_total / float(resampling_rate)
-    edge = int(round(resampling_rate * EDGE_SEC))
-    if left_sec < 0:
-        return 0, min(edge, n_total)
-    if right_sec > duration:
-        return max(n_total - edge, 0), n_total
-    return int(round(left_sec * resampling_rate)), int(round(right_sec * resampling_rate))
+    """One sample's [left, right) range: see sound_slice_bounds_batch."""
+    l, r = sound_slice_bounds_batch([start_frame], [idx], [fps_spec], [n_total], resampling_rate)[0]
+    return int(l), int(r)
 
 
 def extract_sound_features(recordings: Sequence[torch.Tensor], rec_index: Sequence[int], start_frame: Sequence[int],
@@ -125,8 +135,7 @@ def extract_sound_features(recordings: Sequence[torch.Tensor], rec_index: Sequen
     if recs:
         starts[1:] = np.cumsum(lengths[:-1])
     packed = torch.cat(recs) if recs else torch.empty(0, dtype=el, device=dev)
-    bounds = [sound_slice_bounds(start_frame[i], idx[i], fps_spec[i], lengths[rec_index[i]], resampling_rate)
-              for i in range(len(rec_index))]
+    bounds = sound_slice_bounds_batch(start_frame, idx, fps_spec, [lengths[i] for i in rec_index], resampling_rate).reshape(-1, 2).tolist()
     sizes = [r - l for l, r in bounds]
     n = max(sizes) if sizes else 0
     ragged = len(set(sizes)) > 1

@@ -17,6 +17,16 @@ What pins what
                       numpy.fft.rfft evaluation on explicitly framed data as a cross-check
   logmel.npz          long-utterance log-mel (not in the reference): oracle restatement vs
                       transformers.WhisperFeatureExtractor
+  epic_slices.npz     (left, right) sample ranges chosen by the reference's own EPICKitchen._extract_sound_feature
+                      (classification/recognition/dataset/epic_kitchen.py:128-154), executed from the reference file:
+                      the method definition alone is compiled from the file's AST (the module import needs librosa,
+                      torchvision, h5py and a pickle) and called on a stub `self` whose audio dictionary holds
+                      numpy.arange recordings and whose _log_specgram returns its argument, so the returned slice
+                      names its own bounds  -> PINNED (integer index work, bit exact)
+  spec_transform.npz  outputs of the reference's own Stack -> ToTorchFormatTensor(div=True) -> GroupNormalize([0],[1])
+                      (classification/recognition/dataset/transform.py:253-285, 63-76; wired at epic_kitchen.py:62-66),
+                      class definitions compiled from the file's AST, fed the mode-'F' PIL image epic_kitchen.py:176
+                      builds  -> PINNED
 Inputs are regenerated from tests/conftest.synth (integer PRNG), so no waveform is stored.
 """
 import ast
@@ -129,6 +139,93 @@ def epic():
     print("epic_logspec.npz", len(out), "arrays")
 
 
+def _reference_defs(rel_path, names, ns):
+    """Compiles the named top-level functions / classes, or `Class.method` definitions, of one reference file from its AST
+    into `ns` (nothing else of the file is executed) and returns them in order."""
+    tree = ast.parse(open(os.path.join(REF, rel_path)).read())
+    out = []
+    for name in names:
+        cls, _, meth = name.partition(".")
+        node = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name == cls][0]
+        if meth:
+            node = [n for n in node.body if isinstance(n, ast.FunctionDef) and n.name == meth][0]
+        exec(compile(ast.Module(body=[node], type_ignores=[]), "reference:" + name, "exec"), ns)
+        out.append(ns[node.name])
+    return out
+
+
+EPIC_SLICE_SR = 24000
+
+
+def epic_slice_cases():
+    """(start_frame, idx, fps, n_total) rows: both edge clamps, the first / last interior positions, .5-rounding ties of
+    left_sec * 24000 (fps 50 and 60 put centres on multiples of 1/50, 1/60 s: 0.639 * 24000 = 15336 exactly, so a tie needs
+    centre * 24000 = k + 0.5, i.e. odd multiples of 1/48000 s - fps 50 / 60 never give one, fps 29.97 and 23.976 do not
+    either; ties are forced with synthetic fps values), recordings shorter than one edge slice, fps 50 / 60."""
+    rows = []
+    for fps in (50.0, 60.0):
+        for n_total in (24000 * 60, 24000 * 7 + 123, 30696, 30697, 40000, 20000, 1):
+            dur_frames = int(n_total / EPIC_SLICE_SR * fps)
+            for centre in sorted({0, 1, 2, int(0.639 * fps), int(0.639 * fps) + 1, int(0.64 * fps) + 1, dur_frames // 2, dur_frames // 3,
+                                  dur_frames - int(0.639 * fps) - 1, dur_frames - int(0.639 * fps), dur_frames - 1, dur_frames, dur_frames + 5}):
+                if centre < 0:
+                    continue
+                rows.append((centre // 2, centre - centre // 2, fps, n_total))
+    # forced ties: centre_sec * 24000 = k + 0.5  <=>  (start + idx) / fps = (2k + 1) / 48000
+    for k in (20000, 20001, 33333, 100000, 100001):
+        rows.append((2 * k + 1, 0, 48000.0, 24000 * 20))
+        rows.append((k, k + 1, 48000.0, 24000 * 20))
+    # non-integer fps as video_records may hold
+    for fps in (29.97, 23.976, 59.94):
+        for centre in (0, 19, 20, 500, 1000, 1797, 1798):
+            rows.append((centre, 3, fps, 24000 * 61))
+    return rows
+
+
+def epic_slices():
+    import types
+    (ref_fn,) = _reference_defs("classification/recognition/dataset/epic_kitchen.py", ["EPICKitchen._extract_sound_feature"], {"np": np})
+    (ret_fn,) = _reference_defs("classification/retrieval/dataset/epic_kitchen.py", ["EPICKitchen._extract_sound_feature"], {"np": np})
+    rows = epic_slice_cases()
+    res = []
+    for fn in (ref_fn, ret_fn):
+        got = []
+        for start_frame, idx, fps, n_total in rows:
+            stub = types.SimpleNamespace(use_audio_dict=True, audio_path={"rec": np.arange(n_total, dtype=np.int64)},
+                                         resampling_rate=EPIC_SLICE_SR, _log_specgram=lambda s: s)
+            record = types.SimpleNamespace(start_frame=start_frame, fps={"Spec": fps}, untrimmed_video_name="rec")
+            sl = fn(stub, record, idx)
+            got.append((int(sl[0]), int(sl[-1]) + 1) if len(sl) else (0, 0))
+        res.append(got)
+    assert res[0] == res[1], "recognition/ and retrieval/ copies disagree"
+    cases = np.array([(a, b, c, d) for a, b, c, d in rows], dtype=np.float64)
+    bounds = np.array(res[0], dtype=np.int64)
+    lens = bounds[:, 1] - bounds[:, 0]
+    print("epic_slices.npz", len(rows), "cases; slice lengths", sorted(set(lens.tolist())))
+    np.savez_compressed(os.path.join(HERE, "epic_slices.npz"), cases=cases, bounds=bounds)
+
+
+def spec_transform():
+    from PIL import Image
+    ns = {"np": np, "torch": torch}
+    Stack, ToTorchFormatTensor, GroupNormalize = _reference_defs(
+        "classification/recognition/dataset/transform.py", ["Stack", "ToTorchFormatTensor", "GroupNormalize"], ns)
+    chain = [Stack(), ToTorchFormatTensor(), GroupNormalize([0], [1])]       # epic_kitchen.py:62-66 with input_mean / input_std of 'Spec' (:37)
+    out = {}
+    for i, (shape, seed) in enumerate([((256, 256), 31), ((17, 9), 32), ((1, 1), 33)]):
+        rng = np.random.default_rng(seed)
+        spec = (rng.integers(-(1 << 22), 1 << 22, size=shape).astype(np.float64) / float(1 << 18)).astype(np.float32)   # ln-power range -16 .. 16
+        x = [Image.fromarray(spec)]                                          # epic_kitchen.py:176
+        assert x[0].mode == "F"
+        for t in chain:
+            x = t(x)
+        assert tuple(x.shape) == (1,) + shape and x.dtype == torch.float32
+        out[f"c{i}_seed_shape"] = np.array([seed, shape[0], shape[1]])
+        out[f"c{i}_out"] = x.numpy()
+    np.savez_compressed(os.path.join(HERE, "spec_transform.npz"), **out)
+    print("spec_transform.npz", {k: v.shape for k, v in out.items()})
+
+
 def logmel():
     from transformers import WhisperFeatureExtractor
     fe = WhisperFeatureExtractor()
@@ -165,3 +262,5 @@ if __name__ == "__main__":
     epic()
     logmel()
     resample()
+    epic_slices()
+    spec_transform()

@@ -228,6 +228,61 @@ def test_epic_batch_div255_and_slices(mm, O):
         assert np.abs(got[i] - ref).max() <= 1e-4 / 255 + 1e-7
 
 
+def test_epic_slices_against_the_reference_function(mm, O):
+    """extract_sound_features against the slice ranges the reference's own _extract_sound_feature cut
+    (tests/golden/epic_slices.npz): the features of every case must equal, bit for bit, those of the fixture's
+    [left, right) range cut on the host and passed as a plain row - the same kernel on the same samples exactly when
+    the device-side slice indices are the fixture's.  Then the whole chain against the oracle on those ranges."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "epic_slices.npz"))
+    cases, bounds = z["cases"], z["bounds"]
+    totals = sorted(set(int(v) for v in cases[:, 3]))
+    recs = {n: synth("noise0.1", n, 900 + i) for i, n in enumerate(totals)}
+    rec_list = [torch.from_numpy(recs[n]) for n in totals]
+    keep = [i for i in range(len(cases)) if bounds[i, 1] - bounds[i, 0] >= 30672]          # whole slices: 256 frames each
+    assert len(keep) >= 50
+    rec_index = [totals.index(int(cases[i, 3])) for i in keep]
+    got = mm.epic.extract_sound_features(rec_list, rec_index, [int(cases[i, 0]) for i in keep], [int(cases[i, 1]) for i in keep],
+                                         [float(cases[i, 2]) for i in keep])
+    assert got.shape == (len(keep), 1, 256, 256)
+    lens = [int(bounds[i, 1] - bounds[i, 0]) for i in keep]
+    rows = np.zeros((len(keep), max(lens)), np.float32)
+    for j, i in enumerate(keep):
+        rows[j, : lens[j]] = recs[int(cases[i, 3])][bounds[i, 0]:bounds[i, 1]]
+    want = mm.log_specgram_batch(torch.from_numpy(rows).cuda(), div255=True, lengths=lens)
+    assert torch.equal(got[:, 0], want)
+    for j in (0, len(keep) // 2, len(keep) - 1):
+        i = keep[j]
+        ref = O.spec_to_tensor(O.log_specgram(recs[int(cases[i, 3])][bounds[i, 0]:bounds[i, 1]])).numpy()
+        assert np.abs(got[j].cpu().numpy() - ref).max() <= 1e-4 / 255 + 1e-7
+    # recordings shorter than one slice: the reference takes all of them
+    short = [i for i in range(len(cases)) if 120 < bounds[i, 1] - bounds[i, 0] < 30672]
+    assert short
+    i = short[0]
+    n = int(cases[i, 3])
+    g = mm.epic.extract_sound_features([torch.from_numpy(recs[n])], [0], [int(cases[i, 0])], [int(cases[i, 1])], [float(cases[i, 2])])
+    ref = O.spec_to_tensor(O.log_specgram(recs[n][bounds[i, 0]:bounds[i, 1]])).numpy()
+    assert g.shape[1:] == ref.shape and np.abs(g[0].cpu().numpy() - ref).max() <= 1e-4 / 255 + 1e-7
+
+
+def test_epic_spec_transform_against_the_reference_classes(mm, O):
+    """The /255 of the kernel epilogue against the reference's own transform chain (tests/golden/spec_transform.npz is its output
+    on a (256, 256) mode-'F' image): spec_to_tensor on a device tensor is a true division, bit exact; the fused epilogue multiplies
+    by the float32 reciprocal, one rounding away (|d| <= 1 ulp of the result)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spec_transform.npz"))
+    seed, h, w = (int(v) for v in z["c0_seed_shape"])
+    spec = (np.random.default_rng(seed).integers(-(1 << 22), 1 << 22, size=(h, w)).astype(np.float64) / float(1 << 18)).astype(np.float32)
+    t = mm.spec_to_tensor(torch.from_numpy(spec).cuda())
+    assert t.is_cuda and np.array_equal(t.cpu().numpy(), z["c0_out"])
+    x = synth("noise0.1", 30672, 77)
+    raw = mm.log_specgram_batch(torch.from_numpy(x)[None].cuda())
+    fused = mm.log_specgram_batch(torch.from_numpy(x)[None].cuda(), div255=True)
+    chain = mm.spec_to_tensor(raw[0])                  # the reference's order: log spectrogram, then the transform chain
+    d = (fused - chain).abs()
+    assert (d <= torch.finfo(torch.float32).eps * chain.abs()).all()
+
+
 def test_epic_mixed_slice_lengths_one_launch(mm, O):
     """A batch that mixes interior (30 672 +- 1 samples) and edge (30 696) slices, as a DataLoader batch of the reference
     does (epic_kitchen.py:143-154): ONE call, each row equal to its own per-slice oracle within 1e-4 / 255."""
