@@ -101,10 +101,31 @@ def host_core_share() -> int:
     return max(1, min(n, 16))
 
 
-def cpu_baseline(budget_s: float = 12.0, max_clips: int = 200000, legs=("1_thread", "4_workers", "all_cores")):
-    """The CPU restatement of the reference's per-clip front-end (oracle, kind 'port') timed three ways: one thread,
-    4 worker processes (how the reference runs it: DataLoader(num_workers=4), vggsound.py:87) and one worker per
-    available core.  `value` / `cores` at the top level are the 4-worker leg when it ran, else the single thread."""
+def _cpu_c_openmp(budget_s: float, threads: int, max_clips: int = 10 ** 9):
+    """The compiled leg: oracle/fbank_ref.c (plain C, OpenMP over clips) on batches of 4 clips per thread, `threads` threads,
+    for `budget_s` seconds.  The strongest CPU form of this path that exists here."""
+    import numpy as np
+    from oracle import fbank_ref
+    rng = np.random.default_rng(1234)
+    batch = min(4 * threads, max(1, max_clips))
+    clips = np.clip(0.1 * rng.standard_normal((batch, CLIP_SAMPLES)), -1, 1).astype(np.float32)
+    fbank_ref.preprocessing_audio_batch(clips[: min(batch, threads)], threads=threads)       # warm-up
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        fbank_ref.preprocessing_audio_batch(clips, threads=threads)
+        n += batch
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= max_clips:
+            break
+    return n, el
+
+
+def cpu_baseline(budget_s: float = 12.0, max_clips: int = 200000, legs=("1_thread", "4_workers", "all_cores", "c_openmp_all_cores")):
+    """The CPU restatement of the reference's per-clip front-end (oracle, kind 'port') timed four ways: one thread,
+    4 worker processes (how the reference runs it: DataLoader(num_workers=4), vggsound.py:87), one worker per
+    available core, and the compiled C / OpenMP restatement on every available core (the best CPU number, batch calls).
+    `value` / `cores` at the top level are the 4-worker leg when it ran, else the single thread."""
     per_leg = budget_s / max(1, len(legs))
     res = {"unit": "clips/s", "kind": "port", "legs": {}}
     if "1_thread" in legs:
@@ -117,6 +138,14 @@ def cpu_baseline(budget_s: float = 12.0, max_clips: int = 200000, legs=("1_threa
         c = host_core_share()
         n, rate = _cpu_workers(c, per_leg)
         res["legs"]["all_cores"] = {"value": round(rate, 2), "cores": c, "clips": n, "seconds": round(per_leg, 2)}
+    if "c_openmp_all_cores" in legs:
+        c = host_core_share()
+        try:
+            n, el = _cpu_c_openmp(per_leg, c, max_clips)
+            res["legs"]["c_openmp_all_cores"] = {"value": round(n / el, 2), "cores": c, "clips": n, "seconds": round(el, 2),
+                                                 "what": "oracle/fbank_ref.c, gcc -O3 -mavx2 -fopenmp, batches of 4 clips per thread"}
+        except Exception as exc:      # the library is built by __graft_entry__.build(); report rather than fail the line
+            res["legs"]["c_openmp_all_cores"] = {"error": repr(exc)}
     head = "4_workers" if "4_workers" in res["legs"] else next(iter(res["legs"]))
     res["value"] = res["legs"][head]["value"]
     res["cores"] = res["legs"][head]["cores"]
@@ -144,6 +173,9 @@ def load_traffic(kernel_avg_ms: float):
     return prof.get("hbm_bytes_per_launch"), None
 
 
+TRAFFIC_SOURCE = "profiles/fbank_pmc_latest.json (rocprofv3 --pmc passes of an earlier run of this command, replayed; not measured in this run)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,7 +186,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true", help="multi-GPU: skip the separately timed all-gather of features")
     ap.add_argument("--no-secondary", action="store_true", help="skip the HAR / long-utterance / EPIC / 16-bit PCM / resampler configurations")
-    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--cpu-budget", type=float, default=16.0)
     ap.add_argument("--precondition", type=float, default=0.5, help="seconds of untimed launches before the warm-up steps")
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -234,31 +266,40 @@ def main():
     gather = None
     if use_dist and not args.no_allgather:
         try:
-            full = torch.empty((world * B,) + cfg["out"], device=dev)
-            for _ in range(2):
-                dist.all_gather_into_tensor(full, out)
-            fence()
-            k = max(3, min(args.steps, 10))
-            t0 = time.perf_counter()
-            for _ in range(k):
-                step()
-                dist.all_gather_into_tensor(full, out)
-            fence()
-            el = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            for _ in range(k):
-                dist.all_gather_into_tensor(full, out)
-            fence()
-            el_g = time.perf_counter() - t0
-            t = torch.tensor([el, el_g], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el, el_g = (float(v) for v in t.tolist())
+            from multi_modal_amd import partition
+            n_items = world * B
+            full = torch.empty((n_items,) + cfg["out"], device=dev)
             recv = (world - 1) * out.numel() * 4
-            gather = {cfg["unit"].replace("/s", "_per_s_with_allgather"): round(world * B * k / el, 1),
-                      "ms_per_step_with_allgather": round(1e3 * el / k, 3), "allgather_ms": round(1e3 * el_g / k, 3),
-                      "received_bytes_per_rank": recv, "gathered_GB_per_s_per_rank": round(recv * k / el_g / 1e9, 1),
-                      "frac_of_xgmi_7x153GBs": round(recv * k / el_g / 1e9 / XGMI_PEAK_GBS, 4), "steps": k}
-            gather["clips_per_s_with_allgather"] = gather[cfg["unit"].replace("/s", "_per_s_with_allgather")]
+            k = max(3, min(args.steps, 10))
+            modes = {}
+            for mode in ("collective", "direct"):          # the library's all-gather, and shards sent point-to-point to every peer
+                def gather_once(mode=mode):
+                    partition.all_gather_features(out, n_items, out=full, mode=mode)
+                for _ in range(2):
+                    gather_once()
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(k):
+                    step()
+                    gather_once()
+                fence()
+                el = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                for _ in range(k):
+                    gather_once()
+                fence()
+                el_g = time.perf_counter() - t0
+                t = torch.tensor([el, el_g], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el, el_g = (float(v) for v in t.tolist())
+                modes[mode] = {cfg["unit"].replace("/s", "_per_s_with_allgather"): round(world * B * k / el, 1),
+                               "ms_per_step_with_allgather": round(1e3 * el / k, 3), "allgather_ms": round(1e3 * el_g / k, 3),
+                               "gathered_GB_per_s_per_rank": round(recv * k / el_g / 1e9, 1),
+                               "frac_of_xgmi_7x153GBs": round(recv * k / el_g / 1e9 / XGMI_PEAK_GBS, 4)}
+            picked = partition.pick_gather_mode("auto", world, True, True)
+            gather = dict(modes[picked])
+            gather.update({"received_bytes_per_rank": recv, "steps": k, "auto_picks": picked, "modes": modes,
+                           "clips_per_s_with_allgather": modes[picked][cfg["unit"].replace("/s", "_per_s_with_allgather")]})
             del full
         except Exception as exc:      # the headline measurement above is complete: report it whatever happens here
             gather = {"error": repr(exc)}
@@ -289,6 +330,8 @@ def main():
                          "kernel_min_ms": round(kernel_ms[0], 4), "kernel_median_ms": round(kernel_ms[len(kernel_ms) // 2], 4),
                          "algorithmic_bytes_per_unit": cfg["bytes_per_unit"], "units_per_launch": B},
         }
+        if traffic is not None:
+            res["roofline"]["traffic_source"] = TRAFFIC_SOURCE
         if traffic_note:
             res["roofline"]["traffic_note"] = traffic_note
         if gather is not None:

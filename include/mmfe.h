@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define MMFE_ABI_VERSION 5
+#define MMFE_ABI_VERSION 6
 
 /* error codes */
 #define MMFE_OK            0
@@ -113,6 +113,12 @@ extern "C" {
                            (classification/recognition/dataset/epic_kitchen.py:135) make of the 16-bit FLAC / pcm_s16le
                            WAV files the reference stores (vggsound.py:120, recognition/dataset/extract_audio.py:9);
                            FBANK, LOGSPEC and RESAMPLE kinds */
+#define MMFE_IN_F64   2  /* FRAME kind only: frame_signal multiplies in the dtype of its operands
+                           (classification/vggsound/utils/transforms.py:24-25, 58-59), so float64 rows take a float64 window
+                           (spec.window_f64 = 1) and give float64 frames, one correctly rounded product each */
+#define MMFE_IN_F16   3  /* FRAME kind only: IEEE half rows, float window holding half values, half frames (the exact product
+                           rounded once to nearest even, as torch multiplies halves) */
+#define MMFE_IN_BF16  4  /* FRAME kind only: bfloat16 rows, likewise */
 
 typedef struct mmfe_spec {
     int32_t struct_size;   /* = sizeof(mmfe_spec) */
@@ -142,7 +148,8 @@ typedef struct mmfe_spec {
     int32_t window_f64;    /* 1: the `window` argument of mmfe_plan_create points to doubles (librosa / scipy build
                               their windows in float64 and multiply in float64); 0: floats */
     int32_t out_dtype;     /* MMFE_OUT_*: the arithmetic stays float32, only the stored value is rounded */
-    int32_t in_dtype;      /* MMFE_IN_*: results are bit-identical to running on the decoded float32 samples */
+    int32_t in_dtype;      /* MMFE_IN_*: 16-bit PCM results are bit-identical to running on the decoded float32 samples; the FRAME
+                              kind stores frames of its rows' own type */
 } mmfe_spec;
 
 typedef struct mmfe_plan mmfe_plan;

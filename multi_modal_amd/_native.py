@@ -17,14 +17,14 @@ _lib = None
 _lib_lock = threading.Lock()
 
 # --- constants mirrored from include/mmfe.h -------------------------------------------------------
-ABI_VERSION = 5
+ABI_VERSION = 6
 KIND_FBANK, KIND_LOGSPEC, KIND_STFT_MAG, KIND_FRAME, KIND_RESAMPLE = 1, 2, 3, 4, 5
 PAD_NONE, PAD_ZERO, PAD_REFLECT = 0, 1, 2
 FRAMES_SNIP, FRAMES_CENTER, FRAMES_SCIPY, FRAMES_CEIL = 0, 1, 2, 3
 LOG_NONE, LOG_LN_MAX, LOG_LN_ADD, LOG_LOG10_MAX = 0, 1, 2, 3
 LAYOUT_TIME_MAJOR, LAYOUT_FEAT_MAJOR = 0, 1
 OUT_F32, OUT_F16, OUT_BF16 = 0, 1, 2
-IN_F32, IN_S16 = 0, 1
+IN_F32, IN_S16, IN_F64, IN_F16, IN_BF16 = 0, 1, 2, 3, 4
 NOALLOC_MAX_ROWS = 65536
 
 EXPORTED_SYMBOLS = (

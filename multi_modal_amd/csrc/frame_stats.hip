@@ -19,13 +19,39 @@ namespace {
 
 struct FrameArgs {
     RowSource src;
-    float* out;
-    const float* window;
+    void* out;              // elements of the input's type
+    const void* window;     // doubles for float64 rows, floats otherwise
     int64_t n_rows;
     int n_samples, n_frames, frame_len, hop, left_pad;
 };
 
+// Element types of frame_signal.  The reference multiplies in the dtype of its operands (transforms.py:58-59):
+// float32 and float64 products are single correctly rounded operations; a float16 / bfloat16 product is the exact product
+// (at most 22 significant bits, it fits float32) rounded once to 16 bits, which is what torch computes for those dtypes.
+template <int IN_DTYPE> struct FrameElem;
+template <> struct FrameElem<MMFE_IN_F32> {
+    typedef float store; typedef float win;
+    static __device__ __forceinline__ float mul(float v, float w) { return v * w; }
+};
+template <> struct FrameElem<MMFE_IN_F64> {
+    typedef double store; typedef double win;
+    static __device__ __forceinline__ double mul(double v, double w) { return v * w; }
+};
+template <> struct FrameElem<MMFE_IN_F16> {
+    typedef _Float16 store; typedef float win;
+    static __device__ __forceinline__ _Float16 mul(_Float16 v, float w) { return static_cast<_Float16>((float)v * w); }
+};
+template <> struct FrameElem<MMFE_IN_BF16> {
+    typedef unsigned short store; typedef float win;
+    static __device__ __forceinline__ unsigned short mul(unsigned short v, float w) { return bf16_bits(__uint_as_float((unsigned)v << 16) * w); }
+};
+
+template <int IN_DTYPE>
 __global__ void __launch_bounds__(256) frame_kernel(const FrameArgs p) {
+    typedef FrameElem<IN_DTYPE> E;
+    typedef typename E::store T;
+    const typename E::win* window = static_cast<const typename E::win*>(p.window);
+    T* out = static_cast<T*>(p.out);
     const int64_t per_row = (int64_t)p.n_frames * p.frame_len;
     const int64_t total = p.n_rows * per_row;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -34,9 +60,9 @@ __global__ void __launch_bounds__(256) frame_kernel(const FrameArgs p) {
         const int f = rem / p.frame_len;
         const int j = rem - f * p.frame_len;
         const int idx = f * p.hop + j - p.left_pad;
-        float v = 0.f;
-        if (idx >= 0 && idx < p.n_samples) v = row_ptr(p.src, row)[idx];
-        p.out[i] = v * p.window[j];
+        T v = T(0);
+        if (idx >= 0 && idx < p.n_samples) v = row_ptr_as<T>(p.src, row)[idx];
+        out[i] = E::mul(v, window[j]);
     }
 }
 
@@ -127,7 +153,7 @@ int grid_for(int64_t total, int per_block) {
 }  // namespace
 
 int frame_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames,
-                 float* out, hipStream_t stream) {
+                 void* out, hipStream_t stream) {
     const mmfe_spec& s = plan.spec;
     if (n_rows <= 0 || n_frames <= 0) return MMFE_OK;
     if (n_samples >= (int64_t)1 << 30 || n_frames * (int64_t)s.win_len >= (int64_t)1 << 31) {
@@ -137,7 +163,7 @@ int frame_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t
     FrameArgs a{};
     a.src = src;
     a.out = out;
-    a.window = plan.d_window;
+    a.window = s.in_dtype == MMFE_IN_F64 ? static_cast<const void*>(plan.d_window64) : static_cast<const void*>(plan.d_window);
     a.n_rows = n_rows;
     a.n_samples = (int)n_samples;
     a.n_frames = (int)n_frames;
@@ -146,7 +172,14 @@ int frame_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t
     const int64_t pad_len = (n_frames - 1) * s.hop + s.win_len;
     a.left_pad = pad_len > n_samples ? (int)((pad_len - n_samples) / 2) : 0;
     const int64_t total = n_rows * n_frames * s.win_len;
-    hipLaunchKernelGGL(frame_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, a);
+    const dim3 grid(grid_for(total, 256));
+    switch (s.in_dtype) {
+        case MMFE_IN_F32: hipLaunchKernelGGL(frame_kernel<MMFE_IN_F32>, grid, dim3(256), 0, stream, a); break;
+        case MMFE_IN_F64: hipLaunchKernelGGL(frame_kernel<MMFE_IN_F64>, grid, dim3(256), 0, stream, a); break;
+        case MMFE_IN_F16: hipLaunchKernelGGL(frame_kernel<MMFE_IN_F16>, grid, dim3(256), 0, stream, a); break;
+        case MMFE_IN_BF16: hipLaunchKernelGGL(frame_kernel<MMFE_IN_BF16>, grid, dim3(256), 0, stream, a); break;
+        default: set_error("frame: unsupported in_dtype %d", s.in_dtype); return MMFE_EINVAL;
+    }
     MMFE_HIP_CHECK(hipGetLastError());
     return MMFE_OK;
 }

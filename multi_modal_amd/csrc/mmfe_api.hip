@@ -89,9 +89,17 @@ int validate_spec(const mmfe_spec* s) {
     }
     if (s->out_frames < 0) { set_error("out_frames must be >= 0"); return MMFE_EINVAL; }
     if (s->out_dtype < MMFE_OUT_F32 || s->out_dtype > MMFE_OUT_BF16) { set_error("unknown out_dtype"); return MMFE_EINVAL; }
-    if (s->in_dtype != MMFE_IN_F32 && s->in_dtype != MMFE_IN_S16) { set_error("unknown in_dtype"); return MMFE_EINVAL; }
-    if (s->in_dtype != MMFE_IN_F32 && s->kind != MMFE_KIND_FBANK && s->kind != MMFE_KIND_LOGSPEC && s->kind != MMFE_KIND_RESAMPLE) {
+    if (s->in_dtype < MMFE_IN_F32 || s->in_dtype > MMFE_IN_BF16) { set_error("unknown in_dtype"); return MMFE_EINVAL; }
+    if (s->in_dtype == MMFE_IN_S16 && s->kind != MMFE_KIND_FBANK && s->kind != MMFE_KIND_LOGSPEC && s->kind != MMFE_KIND_RESAMPLE) {
         set_error("16-bit PCM input is implemented for the FBANK, LOGSPEC and RESAMPLE kinds only");
+        return MMFE_EINVAL;
+    }
+    if (s->in_dtype > MMFE_IN_S16 && s->kind != MMFE_KIND_FRAME) {
+        set_error("float64 / float16 / bfloat16 rows are taken by the FRAME kind only");
+        return MMFE_EINVAL;
+    }
+    if (s->kind == MMFE_KIND_FRAME && (s->in_dtype == MMFE_IN_S16 || s->out_dtype != MMFE_OUT_F32)) {
+        set_error("FRAME: rows are float32, float64, float16 or bfloat16 and the frames have the rows' type (out_dtype stays 0)");
         return MMFE_EINVAL;
     }
     return MMFE_OK;
@@ -202,7 +210,7 @@ int run_common(const Plan* plan, const RowSource& src, int64_t n_rows, int64_t n
         case IMPL_DFT_GENERIC: rc = dftgen_launch(*plan, src, n_rows, n_samples, natural, frames, out, cs, stream); break;
         case IMPL_RFFT400: rc = rfft400_launch(*plan, src, n_rows, n_samples, natural, frames, out, cs, stream); break;
         case IMPL_STFT32: rc = stft32_launch(*plan, src, n_rows, n_samples, frames, out, stream); break;
-        case IMPL_FRAME: rc = frame_launch(*plan, src, n_rows, n_samples, frames, out, stream); break;
+        case IMPL_FRAME: rc = frame_launch(*plan, src, n_rows, n_samples, frames, out_any, stream); break;
         case IMPL_RESAMPLE: rc = resample_launch(*plan, src, n_rows, n_samples, natural, frames, out, stream); break;
         default: set_error("plan has no implementation"); rc = MMFE_EINVAL;
     }
@@ -338,14 +346,15 @@ int mmfe_plan_create(const mmfe_spec* spec, const void* window, const int32_t* b
         case MMFE_KIND_FRAME:
             if (spec->frames_mode != MMFE_FRAMES_CEIL) { set_error("FRAME: needs MMFE_FRAMES_CEIL"); rc = MMFE_EINVAL; break; }
             p->impl = IMPL_FRAME;
-            rc = upload(&p->d_window, p->window);
+            rc = spec->in_dtype == MMFE_IN_F64 ? upload(&p->d_window64, p->window64) : upload(&p->d_window, p->window);
             break;
         default:
             rc = MMFE_EINVAL;
     }
     if (rc == MMFE_OK && spec->out_dtype != MMFE_OUT_F32 &&
-        !(p->impl == IMPL_FBANK512 || p->impl == IMPL_RFFT400 || (p->impl == IMPL_DFT_GENERIC && !(spec->clamp_below_max > 0.f)))) {
-        set_error("16-bit output is implemented by the log-mel / log-spectrogram kernels (n_fft 512, n_fft 400, any-length DFT without clamp_below_max)");
+        !((spec->kind == MMFE_KIND_FBANK || spec->kind == MMFE_KIND_LOGSPEC) &&
+          (p->impl == IMPL_FBANK512 || p->impl == IMPL_RFFT400 || (p->impl == IMPL_DFT_GENERIC && !(spec->clamp_below_max > 0.f))))) {
+        set_error("16-bit output is implemented for the FBANK and LOGSPEC kinds (n_fft 512, n_fft 400, any-length DFT without clamp_below_max)");
         rc = MMFE_EINVAL;
     }
     if (rc) { free_plan(p); return rc; }

@@ -182,7 +182,7 @@ int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64
                    int64_t out_frames, float* out, const ClampScratch& cs, hipStream_t stream);
 
 int frame_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64_t n_samples, int64_t n_frames,
-                 float* out, hipStream_t stream);
+                 void* out, hipStream_t stream);
 
 // polyphase resampler (MMFE_KIND_RESAMPLE): d_window holds the [up][taps per phase] bank
 int resample_prepare(Plan& plan);

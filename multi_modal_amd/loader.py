@@ -81,7 +81,13 @@ class DevicePrefetcher:
             idx += 1
             if i >= len(slot.pinned) or slot.pinned[i].shape != t.shape or slot.pinned[i].dtype != t.dtype:
                 pinned = torch.empty(t.shape, dtype=t.dtype).pin_memory()
-                dev = torch.empty(t.shape, dtype=t.dtype, device=self.device)
+                # Allocated ON the copy stream: the caching allocator hands out blocks per stream, so a block the caller's
+                # stream freed a moment ago (a temporary that kernels still queued there read) cannot come back here and be
+                # overwritten by the copy.  The caller's stream reads the buffer later; record_stream tells the allocator, so
+                # the block is not recycled for the copy stream while those reads are pending once the set is replaced.
+                with torch.cuda.stream(self.copy_stream):
+                    dev = torch.empty(t.shape, dtype=t.dtype, device=self.device)
+                dev.record_stream(torch.cuda.current_stream(self.device))
                 if i >= len(slot.pinned):
                     slot.pinned.append(pinned)
                     slot.device.append(dev)

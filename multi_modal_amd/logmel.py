@@ -21,7 +21,8 @@ from .plans import IN_CODES, OUT_CODES, cached_plan, run_rows, to_device_rows
 def _plan(device: int, n_fft: int, hop: int, n_mels: int, sr: int, f64: bool, in_dtype: int = N.IN_F32, stream: int = 0,
           out_dtype: int = N.OUT_F32) -> N.Plan:
     # A plan with clamp_below_max owns the per-row extremes its two passes exchange, so two calls on one plan must not
-    # overlap on the device: the cache keeps one plan per HIP stream (calls on one stream are ordered).
+    # overlap on the device: the cache keeps one plan per HIP stream (calls on one stream are ordered), at most _MAX_STREAM_PLANS
+    # of them (each holds an 8 MiB row-extreme scratch; code that keeps creating streams reuses the oldest entries' slots).
     key = ("logmel", n_fft, hop, n_mels, sr, f64, int(in_dtype), int(stream), int(out_dtype))
 
     def build(dev: int) -> N.Plan:
@@ -33,7 +34,10 @@ def _plan(device: int, n_fft: int, hop: int, n_mels: int, sr: int, f64: bool, in
                            layout=N.LAYOUT_FEAT_MAJOR, window_f64=1 if f64 else 0, in_dtype=in_dtype, out_dtype=out_dtype)
         return N.Plan(spec, melbank.periodic_hann(n_fft), bs, bl, bw, device=dev)
 
-    return cached_plan(key, device, build)
+    return cached_plan(key, device, build, family="logmel", limit=_MAX_STREAM_PLANS)
+
+
+_MAX_STREAM_PLANS = 8
 
 
 def log_mel_spectrogram(waveforms: torch.Tensor, n_fft: int = 400, hop_length: int = 160, n_mels: int = 80,

@@ -3,11 +3,13 @@
 The reference is single-GPU (`torch.cuda.set_device(args.cuda)`, classification/vggsound/vanilla_multi.py:113)
 and builds its spectrogram batches with DataLoader workers (vanilla_multi.py:76-77).  Clips are
 independent, so the front-end shards by contiguous batch ranges with no halo and no reduction; the only
-collective is an all-gather (RCCL over xGMI when the tensors are on GPUs, gloo on CPU in tests) for callers
-that need the whole feature tensor on every rank.
+exchange is an all-gather (RCCL over xGMI when the tensors are on GPUs, gloo on CPU in tests) for callers
+that need the whole feature tensor on every rank, in two forms: the library's all-gather collective, or every
+shard sent point-to-point to every peer (one xGMI link per peer, all links busy at once).
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -30,10 +32,76 @@ def shard_size(n_items: int, world_size: int) -> int:
     return -(-n_items // world_size)
 
 
-def all_gather_features(local: torch.Tensor, n_items: int, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Reassemble the (n_items, ...) feature tensor on every rank from the per-rank shards produced over
-    shard_range().  Shards are padded to the common shard size for one all_gather_into_tensor call and the
-    padding is sliced off afterwards."""
+GATHER_MODES = ("auto", "collective", "direct")
+
+
+def pick_gather_mode(mode: str, world: int, even: bool, on_gpu: bool) -> str:
+    """What "auto" resolves to.  Each MI355X has one xGMI link to each of its 7 peers (about 153 GB/s each), so the bytes a
+    rank must receive, (world - 1) shards, can arrive over world - 1 links at once if every rank sends its shard straight to
+    every peer; a ring moves the same bytes through ONE incoming link per rank.  Which of the two an all-gather collective
+    runs is the library's choice at run time, so:
+      direct      GPU tensors and 3 or more ranks (the links are the bound, use all of them), or shards of unequal size
+                  (every shard lands in its final slot, no padded copy of a shard is made)
+      collective  2 ranks (one peer, one link either way), or CPU tensors with equal shards (tests)
+    MMFE_ALLGATHER_MODE=collective|direct overrides "auto" (measure both with `bench.py --config vgg200k`)."""
+    if mode not in GATHER_MODES:
+        raise ValueError(f"mode must be one of {GATHER_MODES}, got {mode!r}")
+    if mode == "auto":
+        env = os.environ.get("MMFE_ALLGATHER_MODE", "")
+        if env in ("collective", "direct"):
+            return env
+        return "direct" if (not even or (on_gpu and world >= 3)) else "collective"
+    return mode
+
+
+def _gather_collective(local: torch.Tensor, n_items: int, per: int, world: int, group, out: Optional[torch.Tensor]) -> torch.Tensor:
+    """One all_gather_into_tensor.  The collective needs equal contributions: a rank whose shard is short (the tail ranks
+    of an uneven split) contributes a zero-padded copy of it, and the padding at the end of the gathered tensor is sliced off."""
+    tail = tuple(local.shape[1:])
+    if local.shape[0] != per:
+        padded = local.new_zeros((per,) + tail)
+        padded[: local.shape[0]] = local
+        local = padded
+    full_shape = (per * world,) + tail
+    if out is None or tuple(out.shape) != full_shape or not out.is_contiguous():
+        out = local.new_empty(full_shape)
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    return out[:n_items]
+
+
+def _gather_direct(local: torch.Tensor, n_items: int, rank: int, world: int, group, out: Optional[torch.Tensor]) -> torch.Tensor:
+    """Every rank sends its shard to every peer and receives every peer's shard straight into its final slot of the output
+    (one batch of point-to-point operations: grouped send / receive pairs under RCCL, one xGMI link per peer).  No padding,
+    no staging copy; empty shards are skipped on both sides (both sides know every shard's range)."""
+    tail = tuple(local.shape[1:])
+    if out is None or tuple(out.shape[1:]) != tail or out.shape[0] < n_items or not out.is_contiguous():
+        out = local.new_empty((n_items,) + tail)
+    local = local.contiguous()
+    lo, hi = shard_range(n_items, rank, world)
+    ops = []
+    for step in range(1, world):                 # peers in rotating order: at step s every rank sends to rank + s and receives from rank - s
+        dst = (rank + step) % world
+        src = (rank - step) % world
+        if hi > lo:
+            ops.append(dist.P2POp(dist.isend, local, dst if group is None else dist.get_global_rank(group, dst), group))
+        slo, shi = shard_range(n_items, src, world)
+        if shi > slo:
+            ops.append(dist.P2POp(dist.irecv, out[slo:shi], src if group is None else dist.get_global_rank(group, src), group))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    if hi > lo:
+        out[lo:hi].copy_(local)
+    for r in reqs:
+        r.wait()
+    return out[:n_items]
+
+
+def all_gather_features(local: torch.Tensor, n_items: int, group=None, out: Optional[torch.Tensor] = None, mode: str = "auto") -> torch.Tensor:
+    """Reassemble the (n_items, ...) feature tensor on every rank from the per-rank shards produced over shard_range().
+    mode "collective": one all_gather_into_tensor (short tail shards are zero-padded to the common size first);
+    mode "direct": every shard sent point-to-point into its final slot on every peer; "auto": see pick_gather_mode.
+    Both give the same tensor.  `out` is used when it fits (collective: (shard_size * world, ...); direct: (n_items, ...))."""
+    if mode not in GATHER_MODES:
+        raise ValueError(f"mode must be one of {GATHER_MODES}, got {mode!r}")
     if not dist.is_initialized():
         if local.shape[0] != n_items:
             raise ValueError("single process: the local shard must be the whole batch")
@@ -44,25 +112,19 @@ def all_gather_features(local: torch.Tensor, n_items: int, group=None, out: Opti
     lo, hi = shard_range(n_items, rank, world)
     if local.shape[0] != hi - lo:
         raise ValueError(f"rank {rank}: local shard has {local.shape[0]} items, expected {hi - lo}")
-    tail = tuple(local.shape[1:])
-    if local.shape[0] != per:
-        padded = local.new_zeros((per,) + tail)
-        padded[: local.shape[0]] = local
-        local = padded
-    local = local.contiguous()
-    full_shape = (per * world,) + tail
-    if out is None or tuple(out.shape) != full_shape:
-        out = local.new_empty(full_shape)
-    dist.all_gather_into_tensor(out, local, group=group)
-    return out[:n_items]
+    chosen = pick_gather_mode(mode, world, per * world == n_items, local.is_cuda)
+    if chosen == "direct":
+        return _gather_direct(local, n_items, rank, world, group, out)
+    return _gather_collective(local, n_items, per, world, group, out)
 
 
-def sharded_apply(fn: Callable[[torch.Tensor], torch.Tensor], batch: torch.Tensor, gather: bool = True, group=None) -> torch.Tensor:
+def sharded_apply(fn: Callable[[torch.Tensor], torch.Tensor], batch: torch.Tensor, gather: bool = True, group=None,
+                  mode: str = "auto") -> torch.Tensor:
     """Run `fn` (a batched front-end such as preprocessing_audio_batch) on this rank's contiguous shard of
-    `batch` and, if `gather`, return the whole feature tensor on every rank."""
+    `batch` and, if `gather`, return the whole feature tensor on every rank (`mode`: see all_gather_features)."""
     n = batch.shape[0]
     if not dist.is_initialized():
         return fn(batch)
     lo, hi = shard_range(n, dist.get_rank(group), dist.get_world_size(group))
     local = fn(batch[lo:hi])
-    return all_gather_features(local, n, group) if gather else local
+    return all_gather_features(local, n, group, mode=mode) if gather else local

@@ -7,6 +7,7 @@ back, like the reference's per-sample CPU call) or on a GPU (result stays there)
 from __future__ import annotations
 
 import threading
+from collections import OrderedDict
 from typing import Callable, Dict, Hashable, Tuple
 
 import torch
@@ -15,7 +16,7 @@ from . import _native as N
 
 OUT_DTYPES = {N.OUT_F32: torch.float32, N.OUT_F16: torch.float16, N.OUT_BF16: torch.bfloat16}
 OUT_CODES = {v: k for k, v in OUT_DTYPES.items()}
-IN_DTYPES = {N.IN_F32: torch.float32, N.IN_S16: torch.int16}
+IN_DTYPES = {N.IN_F32: torch.float32, N.IN_S16: torch.int16, N.IN_F64: torch.float64, N.IN_F16: torch.float16, N.IN_BF16: torch.bfloat16}
 IN_CODES = {v: k for k, v in IN_DTYPES.items()}
 
 _plans: Dict[Hashable, N.Plan] = {}
@@ -34,14 +35,35 @@ def require_gpu() -> None:
                           "there is no CPU fallback")
 
 
-def cached_plan(key: Hashable, device: int, build: Callable[[int], N.Plan]) -> N.Plan:
+# Plans whose key holds caller data (a frame_signal window, a stream handle) form bounded families: the least recently
+# used plan of a full family is dropped from the cache; its device tables are freed when the last reference to it goes (a
+# thread that is launching it at that moment still holds one, and hipFree waits for kernels already queued).
+_family_limits: Dict[str, int] = {}
+_family_order: Dict[str, "OrderedDict[Hashable, None]"] = {}
+
+
+def cached_plan(key: Hashable, device: int, build: Callable[[int], N.Plan], family: str = None, limit: int = 0) -> N.Plan:
     k = (key, device)
+    evicted = []      # released after the lock is dropped: freeing device tables synchronises with the device
     with _plans_lock:
         plan = _plans.get(k)
         if plan is None:
             plan = build(device)
             _plans[k] = plan
-        return plan
+        if family is not None and limit > 0:
+            order = _family_order.setdefault(family, OrderedDict())
+            order[k] = None
+            order.move_to_end(k)
+            while len(order) > limit:
+                old, _ = order.popitem(last=False)
+                evicted.append(_plans.pop(old, None))
+    del evicted
+    return plan
+
+
+def family_size(family: str) -> int:
+    with _plans_lock:
+        return len(_family_order.get(family, ()))
 
 
 def clear_plans() -> None:
@@ -49,18 +71,20 @@ def clear_plans() -> None:
         for p in _plans.values():
             p.close()
         _plans.clear()
+        _family_order.clear()
 
 
-def to_device_rows(x: torch.Tensor, pcm_ok: bool = False) -> Tuple[torch.Tensor, torch.device]:
+def to_device_rows(x: torch.Tensor, pcm_ok: bool = False, keep_float_dtype: bool = False) -> Tuple[torch.Tensor, torch.device]:
     """(rows, n) float32 tensor with unit inner stride on a GPU, plus the device the caller's data was on.
-    With pcm_ok an int16 tensor stays int16 (16-bit PCM, decoded inside the kernel as s / 32768)."""
+    With pcm_ok an int16 tensor stays int16 (16-bit PCM, decoded inside the kernel as s / 32768); with keep_float_dtype
+    float64 / float16 / bfloat16 rows keep their type (frame_signal)."""
     require_gpu()
     origin = x.device
     if x.dim() != 2:
         raise ValueError(f"expected a 2-D (rows, samples) tensor, got {tuple(x.shape)}")
     if x.dtype == torch.int16 and not pcm_ok:
         raise TypeError("this transform takes float samples; int16 PCM is read by the log-mel and log-spectrogram transforms only")
-    if x.dtype != torch.float32 and x.dtype != torch.int16:
+    if x.dtype != torch.float32 and x.dtype != torch.int16 and not (keep_float_dtype and x.dtype in (torch.float64, torch.float16, torch.bfloat16)):
         x = x.to(torch.float32)
     if not x.is_cuda:
         x = x.cuda(non_blocking=False)
@@ -93,7 +117,7 @@ def run_rows(plan: N.Plan, x: torch.Tensor, out: torch.Tensor = None, lengths=No
     frames, feat = plan.out_shape(n)
     shape = (rows, frames, feat) if plan.spec.layout == N.LAYOUT_TIME_MAJOR or plan.spec.kind == N.KIND_FRAME \
         else (rows, feat, frames)
-    dtype = OUT_DTYPES[plan.spec.out_dtype]
+    dtype = x.dtype if plan.spec.kind == N.KIND_FRAME else OUT_DTYPES[plan.spec.out_dtype]     # frames have their rows' type
     if out is None:
         out = torch.empty(shape, dtype=dtype, device=x.device)
     else:

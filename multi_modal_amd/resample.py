@@ -82,7 +82,9 @@ def resample_batch(waveforms: torch.Tensor, orig_sr: int, target_sr: int, out_sa
 
 def load_resampled(waveforms: torch.Tensor, orig_sr: int, sr: int = 16000, duration: Optional[float] = None) -> torch.Tensor:
     """The resampling half of `librosa.load(file, sr=sr, duration=duration)` (vggsound.py:114) for decoded clips: the first
-    `duration` seconds at the original rate are kept, then converted; (B, n) -> (B, ceil(min(n, duration * orig_sr) * sr / orig_sr))."""
+    `duration` seconds at the original rate are kept, then converted; (B, n) -> (B, ceil(min(n, duration * orig_sr) * sr / orig_sr)).
+    The low-pass is scipy.signal.resample_poly's Kaiser design, not librosa's default soxr_hq (absent here, parity with it
+    unpinned): features computed from these clips differ from the reference's at the level of the resampling filter."""
     if waveforms.dim() == 1:
         return load_resampled(waveforms[None], orig_sr, sr, duration)[0]
     if duration is not None:

@@ -83,8 +83,24 @@ def frame_signal():
         out[f"c{i}_signal"], out[f"c{i}_window"] = s, w
         out[f"c{i}_params"] = np.array([fl, hop])
         out[f"c{i}_out"], out[f"c{i}_out_ones"] = y, y1
+    # the product's dtype follows torch's promotion of signal * window (transforms.py:24-25, 58-59): float64, float16, bfloat16 and
+    # mixed operands, stored as the bit patterns the reference function returned (16-bit types as uint16 views)
+    dt = {"f64": torch.float64, "f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}
+    typed = [("f64", "f64", (2, 50), 16, 5), ("f16", "f16", (3, 41), 8, 3), ("bf16", "bf16", (2, 37), 8, 4), ("f32", "f64", (1, 45), 12, 7),
+             ("f16", "f32", (2, 29), 6, 5), ("f64", None, (1, 23), 9, 2)]
+    for i, (sd, wd, shape, fl, hop) in enumerate(typed):
+        rng = np.random.default_rng(300 + i)
+        s = torch.from_numpy(rng.standard_normal(shape)).to(dt[sd])               # values with full mantissas in the signal's type
+        w = None if wd is None else torch.from_numpy(rng.standard_normal(fl)).to(dt[wd])
+        y = ref_fn(s, fl, hop) if w is None else ref_fn(s, fl, hop, w)
+        bits = lambda t: t.view(torch.int16).numpy().view(np.uint16) if t.dtype in (torch.float16, torch.bfloat16) else t.numpy()
+        out[f"t{i}_signal"], out[f"t{i}_out"] = bits(s), bits(y)
+        if w is not None:
+            out[f"t{i}_window"] = bits(w)
+        out[f"t{i}_params"] = np.array([fl, hop])
+        out[f"t{i}_dtypes"] = np.array([sd, wd or "none", {v: k for k, v in dt.items()}[y.dtype]])
     np.savez_compressed(os.path.join(HERE, "frame_signal.npz"), **out)
-    print("frame_signal.npz", len(cases), "cases")
+    print("frame_signal.npz", len(cases), "float32 cases,", len(typed), "typed cases")
 
 
 def kaldi():

@@ -42,12 +42,15 @@ for lo in range(0, n_clips, 5000):          # generated on the device in slabs (
     hi = min(n_clips, lo + 5000)
     x[lo:hi] = (0.1 * torch.randn(hi - lo, 160000, device=dev, generator=g)).clamp_(-1, 1)
 
-full = partition.sharded_apply(mm.preprocessing_audio_batch, x, gather=True)
+full = partition.sharded_apply(mm.preprocessing_audio_batch, x, gather=True, mode="collective")
 torch.cuda.synchronize()
 assert tuple(full.shape) == (n_clips, 384, 128), full.shape
 assert bool(torch.isfinite(full).all())
 local = partition.sharded_apply(mm.preprocessing_audio_batch, x, gather=False)
 assert torch.equal(full, local)                              # one rank: the gathered tensor is the local shard
+direct = partition.sharded_apply(mm.preprocessing_audio_batch, x, gather=True, mode="direct")
+assert direct.data_ptr() != local.data_ptr() and torch.equal(direct, local)      # the point-to-point form: own shard copied into its slot
+del direct
 pick = torch.tensor([0, 1, 4095, 4096, n_clips // 2, n_clips - 2, n_clips - 1], device=dev)
 small = mm.preprocessing_audio_batch(x[pick].contiguous())
 assert torch.equal(full[pick], small), "features depend on the position in the batch"
@@ -58,8 +61,10 @@ shard = full[:1001].contiguous()
 out = partition.all_gather_features(shard, 1001)
 assert torch.equal(out, shard)
 buf = torch.empty(1001, 384, 128, device=dev)
-out2 = partition.all_gather_features(shard, 1001, out=buf)
-assert out2.data_ptr() == buf.data_ptr() and torch.equal(out2, shard)
+for mode in ("collective", "direct", "auto"):
+    buf.fill_(-1.0)
+    out2 = partition.all_gather_features(shard, 1001, out=buf, mode=mode)
+    assert out2.data_ptr() == buf.data_ptr() and torch.equal(out2, shard), mode
 try:
     partition.all_gather_features(shard, 1002)
     raise SystemExit("a shard of the wrong size was accepted")
@@ -129,3 +134,6 @@ def test_bench_configs_under_one_rank_group(tmp_path):
         assert res["n_gpus"] == 1 and res["value"] > 0 and res["roofline"]["frac"] > 0
         assert "allgather" in res and "error" not in res["allgather"], res.get("allgather")
         assert res["allgather"]["clips_per_s_with_allgather"] > 0
+        for mode in ("collective", "direct"):
+            assert res["allgather"]["modes"][mode]["allgather_ms"] > 0, res["allgather"]
+        assert res["allgather"]["auto_picks"] in ("collective", "direct")

@@ -227,35 +227,47 @@ def test_shard_ranges():
 _WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
-from multi_modal_amd.partition import all_gather_features, shard_range, sharded_apply
-dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=2)
+from multi_modal_amd.partition import all_gather_features, pick_gather_mode, shard_range, sharded_apply
+world = int(sys.argv[4])
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=world)
 rank = dist.get_rank()
-for n in (7, 8, 1):
+for n in (7, 8, 1, 12, 2):
     full = torch.arange(n * 6, dtype=torch.float32).reshape(n, 2, 3)
-    lo, hi = shard_range(n, rank, 2)
-    got = all_gather_features(full[lo:hi].clone(), n)
-    assert torch.equal(got, full), (n, rank)
+    lo, hi = shard_range(n, rank, world)
+    for mode in ("collective", "direct", "auto"):
+        got = all_gather_features(full[lo:hi].clone(), n, mode=mode)
+        assert got.shape == full.shape and torch.equal(got, full), (n, rank, mode)       # bit-equal to the single-process tensor
+    # caller-provided output of the direct form: shards land in their final slots, no other element is touched
+    out = torch.full((n + 2, 2, 3), -1.0)
+    got = all_gather_features(full[lo:hi].clone(), n, out=out, mode="direct")
+    assert got.data_ptr() == out.data_ptr() and torch.equal(out[:n], full) and bool((out[n:] == -1).all())
     # a stand-in front-end (the real one needs a GPU): the partitioner only sees a (B, n) -> (B, f, m) map
     fn = lambda x: torch.stack([x.sum(1, keepdim=True), x.max(1, keepdim=True).values], 1)
     batch = torch.arange(n * 5, dtype=torch.float32).reshape(n, 5)
-    assert torch.equal(sharded_apply(fn, batch), fn(batch))
+    for mode in ("collective", "direct"):
+        assert torch.equal(sharded_apply(fn, batch, mode=mode), fn(batch))
     assert sharded_apply(fn, batch, gather=False).shape[0] == hi - lo
+assert pick_gather_mode("auto", 8, True, True) == "direct" and pick_gather_mode("auto", 2, True, True) == "collective"
+assert pick_gather_mode("auto", 2, False, False) == "direct" and pick_gather_mode("auto", 3, True, False) == "collective"
 dist.barrier()
 dist.destroy_process_group()
 print("ok", rank)
 """
 
 
-def test_partition_all_gather_world2_gloo(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_partition_all_gather_gloo(tmp_path, world):
+    """Both forms of the feature all-gather (the collective, and shards sent point-to-point into their final slots) over gloo with
+    2 and 3 ranks, even and uneven splits, empty tail shards: bit-equal to the single-process tensor."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(port), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-             for r in range(2)]
-    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(port), str(r), str(world)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert "ok" in o
@@ -269,11 +281,13 @@ def test_bench_cpu_baseline_fields():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     assert bench.BYTES_PER_CLIP == 811008 and bench.BYTES_PER_UTT == 2880000
-    r = bench.cpu_baseline(budget_s=0.4, max_clips=3, legs=("1_thread", "4_workers"))
+    r = bench.cpu_baseline(budget_s=0.6, max_clips=3, legs=("1_thread", "4_workers", "c_openmp_all_cores"))
     assert r["unit"] == "clips/s" and r["kind"] == "port" and "clips" in r["sample"]
     assert r["legs"]["1_thread"]["cores"] == 1 and r["legs"]["1_thread"]["value"] > 0
     assert r["legs"]["4_workers"]["cores"] == 4 and r["legs"]["4_workers"]["value"] > 0
     assert r["cores"] == 4 and r["value"] == r["legs"]["4_workers"]["value"]       # the leg the reference's DataLoader corresponds to
+    c = r["legs"]["c_openmp_all_cores"]                                            # the compiled C / OpenMP restatement, every core of the share
+    assert c["cores"] == bench.host_core_share() and c["value"] > 0 and c["clips"] >= 1
     assert 1 <= bench.host_core_share() <= 16
     assert set(bench.CONFIGS) == {"vgg4096", "vgg200k", "logmel"}
 
