@@ -84,7 +84,10 @@ def log_specgram(audio, window_size: int = 10, step_size: int = 5, eps: float = 
 def spec_to_tensor(spec) -> torch.Tensor:
     """The Spec transform chain applied to one (H, W) float image: (1, H, W) / 255, mean 0 / std 1."""
     t = torch.from_numpy(np.ascontiguousarray(spec)) if isinstance(spec, np.ndarray) else spec
-    return (t.to(torch.float32).unsqueeze(0) / 255 - 0.0) / 1.0
+    t = t.to(torch.float32).unsqueeze(0)
+    # a true division, like ToTorchFormatTensor's `.div(255)` on the CPU (transform.py:285): on a GPU torch turns division by a
+    # Python scalar into a multiplication by its reciprocal, one rounding away; a tensor divisor keeps the division
+    return (torch.div(t, t.new_full((), 255.0)) - 0.0) / 1.0
 
 
 def sound_slice_bounds_batch(start_frame, idx, fps_spec, n_total, resampling_rate: int = RESAMPLING_RATE) -> np.ndarray:

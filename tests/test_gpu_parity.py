@@ -267,8 +267,9 @@ def test_epic_slices_against_the_reference_function(mm, O):
 
 def test_epic_spec_transform_against_the_reference_classes(mm, O):
     """The /255 of the kernel epilogue against the reference's own transform chain (tests/golden/spec_transform.npz is its output
-    on a (256, 256) mode-'F' image): spec_to_tensor on a device tensor is a true division, bit exact; the fused epilogue multiplies
-    by the float32 reciprocal, one rounding away (|d| <= 1 ulp of the result)."""
+    on a (256, 256) mode-'F' image): spec_to_tensor on a device tensor is a true division, bit exact; the fused epilogue folds
+    ln 2 / 255 into the one multiplication behind its base-2 logarithm, so it is one rounding (of the natural logarithm) short of
+    the two-step value and one (of the reciprocal) away from the division: |d| <= 2 ulp of the result."""
     import os
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spec_transform.npz"))
     seed, h, w = (int(v) for v in z["c0_seed_shape"])
@@ -280,7 +281,7 @@ def test_epic_spec_transform_against_the_reference_classes(mm, O):
     fused = mm.log_specgram_batch(torch.from_numpy(x)[None].cuda(), div255=True)
     chain = mm.spec_to_tensor(raw[0])                  # the reference's order: log spectrogram, then the transform chain
     d = (fused - chain).abs()
-    assert (d <= torch.finfo(torch.float32).eps * chain.abs()).all()
+    assert (d <= 2 * torch.finfo(torch.float32).eps * chain.abs() + 1e-12).all()
 
 
 def test_epic_mixed_slice_lengths_one_launch(mm, O):
@@ -1396,6 +1397,7 @@ def test_frame_signal_plans_are_cached_by_window(mm, O):
     """Repeated frame_signal calls with equal windows share one plan (no table rebuild, no stream synchronisation); another
     window gets another plan and its own values."""
     from multi_modal_amd import plans
+    plans.clear_plans()              # (the family of frame plans is bounded: start from an empty one)
     x = torch.from_numpy(synth("noise0.1", 4000, 31)).cuda()
     w1 = torch.hann_window(64)
     w2 = torch.hamming_window(64)
