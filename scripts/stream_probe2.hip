@@ -4,6 +4,8 @@
 //   loader  0  frame-shaped 8-byte loads (16 lanes own a frame: 13 loads per lane, 128-byte runs)
 //           1  wave-linear 16-byte loads (64 lanes x 16 B = 1 KiB per instruction, 7 per quad)
 //           2  wave-linear LDS-DMA (global_load_lds_dwordx4) into a per-wave LDS ring, read back by ds_read_b64
+//           3  frame-shaped 16-byte loads (16 lanes own a frame, lane b takes samples 64a + 4b .. + 3: 7 loads per lane, 256-byte
+//              runs): the pattern of a 256 = 8 x 32 split of the transform, where a lane's 16-byte load is its first-stage input
 //   depth   quads in flight per wave beyond the one being consumed (1 or 2)
 //   store   0  4 x 256-byte runs per instruction (the kernel's layout), nontemporal
 //           1  1 KiB contiguous per instruction, nontemporal
@@ -55,6 +57,7 @@ __global__ void __launch_bounds__(256) probe_reg(const float* __restrict__ in, f
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NL = LOADER == 0 ? 13 : 7;
     constexpr int W = LOADER == 0 ? 2 : 4;
+    static_assert(LOADER == 0 || LOADER == 1 || LOADER == 3, "register loaders");
     float buf[DEPTH][NL][W];
     // quads are visited in runs of `chunk` consecutive quads per wave
     const int wid = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
@@ -70,6 +73,13 @@ __global__ void __launch_bounds__(256) probe_reg(const float* __restrict__ in, f
                 const float* p = ok ? qp + fl * 400 + idx : in;
                 f32x2 r = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p)) : *reinterpret_cast<const f32x2*>(p);
                 buf[slot][a][0] = ok ? r.x : 0.f; buf[slot][a][1] = ok ? r.y : 0.f;
+            } else if constexpr (LOADER == 3) {
+                const int fl = lane >> 4, b = lane & 15;
+                const int idx = 64 * a + 4 * b;
+                const bool ok = idx < 400;
+                const float* p = ok ? qp + fl * 400 + idx : in;
+                f32x4 r = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)) : *reinterpret_cast<const f32x4*>(p);
+                buf[slot][a][0] = ok ? r.x : 0.f; buf[slot][a][1] = ok ? r.y : 0.f; buf[slot][a][2] = ok ? r.z : 0.f; buf[slot][a][3] = ok ? r.w : 0.f;
             } else {
                 const int idx = 4 * (64 * a + lane);
                 const bool ok = idx < kQuadFloats;
@@ -203,9 +213,22 @@ int main() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_dma<2, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_dma<1, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 
-#define RUN_REG(L, D, ST, NT, bpc, chunk) report(L == 0 ? "frame8B" : "linear16B", D, ST, NT, bpc, chunk, time_it([&] { probe_reg<L, D, ST, NT><<<256 * (bpc), 256>>>(in, out, n_quads, chunk); }))
+#define RUN_REG(L, D, ST, NT, bpc, chunk) report(L == 0 ? "frame8B" : (L == 3 ? "frame16B" : "linear16B"), D, ST, NT, bpc, chunk, time_it([&] { probe_reg<L, D, ST, NT><<<256 * (bpc), 256>>>(in, out, n_quads, chunk); }))
 #define RUN_DMA(D, ST, NT, bpc, chunk) report("lds-dma", D, ST, NT, bpc, chunk, time_it([&] { probe_dma<D, ST, NT><<<256 * (bpc), 256, 4 * (D + 1) * kSlotBytes>>>(in, out, n_quads, chunk); }))
 
+    // the three register patterns side by side at the kernel's occupancy (3 blocks of 4 waves per CU) and one above it
+    for (int rep = 0; rep < 2; ++rep)
+        for (int bpc : {3, 4}) {
+            RUN_REG(0, 1, 0, false, bpc, 1);
+            RUN_REG(0, 1, 0, true, bpc, 1);
+            RUN_REG(3, 1, 0, false, bpc, 1);
+            RUN_REG(3, 1, 0, true, bpc, 1);
+            RUN_REG(1, 1, 0, false, bpc, 1);
+            RUN_REG(1, 1, 0, true, bpc, 1);
+            RUN_REG(0, 1, 3, true, bpc, 1);
+            RUN_REG(3, 1, 3, true, bpc, 1);
+        }
+    if (getenv("MMFE_PROBE_SHORT")) { (void)hipDeviceSynchronize(); return 0; }
     for (int bpc : {2, 3, 4, 6, 8}) {
         RUN_REG(0, 1, 0, false, bpc, 1);
         RUN_REG(1, 1, 0, false, bpc, 1);
