@@ -534,12 +534,15 @@ int resample_prepare(Plan& plan) {
     // tile take `rounds` turns of (waves per SIMD) runs of wlen * Q each.
     struct Layout { int Q = 0, L = 0, D = 0, groups = 0, wlen = 0, i_max = 0, nb = 0, threads = 0, tile_in = 0, ls = 0; double cost = 0; std::vector<int32_t> gi; std::vector<int> io, ph; };
     Layout best;
-    for (int Q = 4; Q <= 5; ++Q) {
+    // Q = 3 and 7 serve the odd `up` of upsampling ratios (441/160, 147/80, 3/1, 3/2: lanes `up` outputs apart leave whole runs of 3 or 7);
+    // their lane runs are not whole 16-byte pieces, so those tiles are stored 4 bytes per lane (still contiguous rows)
+    for (int Q : {4, 5, 7, 3}) {
         if (force_q != nullptr && std::atoi(force_q) != Q) continue;
         Layout c;
         c.Q = Q;
         const int64_t L = (int64_t)up * ((Q + up - 1) / up);
-        if (L % Q != 0 || L % 4 != 0 || L > 4096) continue;
+        if (L % Q != 0 || L > 4096) continue;
+        if (L % 4 != 0 && Q != 3 && Q != 7) continue;
         c.L = (int)L;
         c.D = (int)(L * down / up);
         c.groups = (int)(L / Q);
@@ -559,7 +562,8 @@ int resample_prepare(Plan& plan) {
         }
         c.wlen = (taps + max_back + 7) & ~7;
         // lane runs in the output area: a multiple of 4 floats whose quarter is odd keeps the 16-byte accesses of 64 lanes on distinct banks
-        c.ls = (L / 4) % 2 == 1 ? (int)L : (int)L + 4;
+        // (runs that are not a multiple of 4 floats are stored float by float: any odd stride is conflict-free)
+        c.ls = L % 4 == 0 ? ((L / 4) % 2 == 1 ? (int)L : (int)L + 4) : (L % 2 == 1 ? (int)L : (int)L + 1);
         // lane blocks per tile: as many as LDS and the prefetch registers hold
         for (int cand = 1; cand <= 64; ++cand) {
             const int64_t t_in = c.wlen + (int64_t)cand * 64 * c.D + c.i_max + 1;
@@ -699,18 +703,24 @@ int resample_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
         a.tiles_per_row = (int)((n_out + a.tile_out - 1) / a.tile_out);
         a.wt = plan.d_tw_a;
         a.gi = plan.d_mel_start;
-        a.vec_out = (reinterpret_cast<uintptr_t>(out) % 16 == 0 && out_len % 4 == 0) ? 1 : 0;
+        a.vec_out = (reinterpret_cast<uintptr_t>(out) % 16 == 0 && out_len % 4 == 0 && a.L % 4 == 0) ? 1 : 0;
         const size_t lds = 4 * ((size_t)((a.tile_in + 3) & ~3) + (size_t)a.nb * 64 * a.ls);
         // whole four-sample pieces: rows on 4-sample boundaries of aligned memory, a multiple of 4 samples each, no per-row lengths
         const bool vec = src.offsets == nullptr && src.row_len == nullptr && n_samples % 4 == 0 && n_samples >= 4 && src.stride % 4 == 0 &&
                          reinterpret_cast<uintptr_t>(src.base) % (pcm ? 8 : 16) == 0;
         typedef void (*phase_fn)(const ResamplePhaseArgs);
-        const phase_fn table[2][2][2] = {
-            {{&resample_phase_kernel<float, 4, false>, &resample_phase_kernel<float, 4, true>},
-             {&resample_phase_kernel<float, 5, false>, &resample_phase_kernel<float, 5, true>}},
-            {{&resample_phase_kernel<int16_t, 4, false>, &resample_phase_kernel<int16_t, 4, true>},
-             {&resample_phase_kernel<int16_t, 5, false>, &resample_phase_kernel<int16_t, 5, true>}}};
-        const phase_fn kfn = table[pcm ? 1 : 0][plan.rs_q == 5 ? 1 : 0][vec ? 1 : 0];
+        auto pick = [&](auto smp_tag) -> phase_fn {
+            typedef decltype(smp_tag) SMP;
+            switch (plan.rs_q) {
+                case 3: return vec ? &resample_phase_kernel<SMP, 3, true> : &resample_phase_kernel<SMP, 3, false>;
+                case 4: return vec ? &resample_phase_kernel<SMP, 4, true> : &resample_phase_kernel<SMP, 4, false>;
+                case 5: return vec ? &resample_phase_kernel<SMP, 5, true> : &resample_phase_kernel<SMP, 5, false>;
+                case 7: return vec ? &resample_phase_kernel<SMP, 7, true> : &resample_phase_kernel<SMP, 7, false>;
+                default: return nullptr;
+            }
+        };
+        const phase_fn kfn = pcm ? pick(int16_t{}) : pick(float{});
+        if (kfn == nullptr) { set_error("RESAMPLE: no kernel for runs of %d outputs", plan.rs_q); return MMFE_EINVAL; }
         int per_cu = 1, cus = 256;
         const int rc = kernel_prepare(reinterpret_cast<const void*>(kfn), plan.rs_threads, lds, &per_cu, &cus);
         if (rc) return rc;
