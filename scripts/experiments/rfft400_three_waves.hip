@@ -1,3 +1,7 @@
+// EXPERIMENT, not part of the library: the n_fft 400 kernel restructured for three waves per SIMD (8 KB of LDS work area per wave through a
+// two-shot XOR-swizzled transpose tile, window and mel weights as LDS tables, <= 168 VGPRs).  Bit-identical outputs; measured SLOWER than
+// two waves per SIMD (profiles/r03_rfft400_occupancy.txt): the same build limited to 2 blocks per CU beats itself at 3.
+// Build: SRCFILE=scripts/experiments/rfft400_three_waves.hip scripts/build_variant_of.sh rfft400 r4late -DMMFE_R400_EARLY_FETCH=0
 // Fused log-mel front-end for n_fft = 400 (25 ms frames at 16 kHz) on gfx950: framing with centre
 // reflect/zero padding or edge snipping -> window -> 400-point real FFT -> |X|^2 -> banded mel ->
 // log -> affine, spectra never leave the CU.  This is the long-utterance configuration
@@ -6,22 +10,23 @@
 //
 // Mapping: 16 lanes own a PAIR of consecutive frames (A, B); a wave64 carries 8 consecutive frames
 // of one row per pass.
-//   * the wave's samples (7*hop + 400 of them) arrive by coalesced 16-byte loads, one pass ahead,
-//     and are laid out in LDS once, so the 2.5x overlap of neighbouring frames never re-reads HBM;
+//   * every lane loads its own strided samples (n = 16a + b of its two frames) straight from global memory, one pass
+//     ahead; the 2.5x overlap of neighbouring frames is served by L1 / L2, so HBM sees every sample about once;
 //   * z[n] = w[n]*(A[n] + i*B[n]) is transformed by ONE 400-point complex FFT, split 25 x 16:
 //     lane b runs a register-resident 25-point FFT (radix 5 x 5) over z[16a+b], twiddles by
-//     W400^(b*c), the 16 lanes transpose through a padded LDS tile, and each lane runs the 16-point
-//     FFTs of columns c = b and c = b+16 (the second only for b <= 8), leaving Z[c + 25d];
+//     W400^(b*c), the 16 lanes transpose through an XOR-swizzled LDS tile in two shots (rows 0..15, then
+//     rows 16..24 in the same place), and each lane runs the 16-point FFTs of columns c = b and c = b+16
+//     (the second only for b <= 8), leaving Z[c + 25d];
 //   * the two real spectra separate as X_A[k] = (Z[k] + conj Z[400-k])/2 and
 //     X_B[k] = (Z[k] - conj Z[400-k])/(2i); the window is pre-halved, so |X_A|^2 and |X_B|^2 are two
 //     sums of squares per bin, written to LDS;
 //   * banded mel on the matrix pipe: v_mfma_f32_4x4x1 runs 16 independent blocks of (4 frames) x
 //     (4 filters); a block walks ITS OWN run of bins, one bin per instruction, weights resident in
-//     VGPRs.  The (filter block, frame group) units are spread over up to four instruction streams
+//     an LDS table.  The (filter block, frame group) units are spread over up to four instruction streams
 //     in order of frequency, so the short low-frequency runs do not wait for the long high ones; a
 //     last stream that is at most half full splits its runs in two and adds the halves.
-// Two waves per SIMD (LDS-bound occupancy) leave 256 VGPRs per lane: the window, the mel weights
-// and the prefetched samples all stay in registers.
+// Three waves per SIMD: 8 KB of LDS work area per wave (the two-shot tile) and at most 168 VGPRs per lane, which is why
+// the window and the mel weights are LDS tables (16-byte reads) and only the prefetched samples stay in registers.
 #include "mmfe_internal.h"
 #include "fft_regs.h"
 #include "log_affine.h"
@@ -32,6 +37,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace mmfe {
@@ -42,34 +48,14 @@ constexpr int kN = 400;
 constexpr int kBins = 201;
 constexpr int kWaves = 4;                           // waves per block
 constexpr int kMaxHop = 160;
-constexpr int kMaxSpan = 7 * kMaxHop + kN;          // samples under one wave pass: 1520
-[[maybe_unused]] constexpr int kPF = (kMaxSpan / 4 + 63) / 64;       // prefetch registers (16-byte) per lane: 6
-constexpr int kTileStride = 18;                     // complex numbers per transpose-tile row (16 + padding, keeps rows 16-byte aligned)
-constexpr int kPairBytes = 25 * kTileStride * 8 + 112;   // 3712: transpose tile / natural-order spectrum of one frame pair; = 32 dwords
-                                                         // mod 64, so the two pairs of a 32-lane half sit on disjoint LDS banks
-constexpr int kWaveBytes = 4 * kPairBytes;          // 14848: one LDS work area per wave, reused by every phase
 constexpr int kPS = 216;                            // floats between the power spectra of consecutive frames (= 24 mod 64: 8 frames on 8 bank groups)
 constexpr int kPGuard = 8;                          // floats in front of bin 0 (a bin run may start below 0)
 constexpr int kTwBytes = 25 * 16 * 8;               // W400^(b*c) table, [c][b]
 constexpr int kStreams = 4;
 
-#ifndef MMFE_R400_DIRECT
-#define MMFE_R400_DIRECT 1      // 1: every lane loads its own strided samples (n = 16a + b of frames A and B) straight from global memory, one
-                                //    pass ahead; the 2.5x overlap of neighbouring frames is served by L1/L2.  0: the wave's samples are staged in LDS
-                                //    by 16-byte loads and gathered from there
-#endif
-#ifndef MMFE_R400_HALFPARK
-#define MMFE_R400_HALFPARK 1    // 1: a lane separates the bins k <= 200 of its own FFT columns, Z[k] from registers; only Z[201..399] is parked
-                                //    in LDS for the partners Z[400 - k].  0: all of Z is parked in natural order and both members are read back
-#endif
-
-#ifndef MMFE_R400_TWGROUP
-#define MMFE_R400_TWGROUP 8
-#endif
-#ifndef MMFE_R400_RANGES
-#define MMFE_R400_RANGES 1      // 1: a block works through one contiguous range of octets, so a wave stays inside a row for many passes and the
-                                //    per-row extremes of clamp_below_max are reduced across the wave once per row instead of once per pass.
-                                //    0: blocks take octets round-robin over the whole batch
+#ifndef MMFE_R400_EARLY_FETCH
+#define MMFE_R400_EARLY_FETCH 1     // shared-load form (hop a multiple of 16): request the next octet's samples right after the first tile shot has
+                                    // been written instead of after the 16-point transforms (35 values in flight fit the register budget there)
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -96,23 +82,7 @@ struct Rfft400Args {
     const int32_t* mel_poff;   // [kStreams][64]: float offset of the lane's bin run in the wave's spectrum area
     const int32_t* mel_dst;    // [kStreams][64]: filter | frame group << 16, or -1 for an idle lane
     const float* mel_w;        // [total steps][64], step-major
-    unsigned long long* stamps;  // diagnostic build only
 };
-
-// Diagnostic build only (-DMMFE_STAMPS): per-phase s_memtime shares of the main loop, printed by the launcher.
-#ifdef MMFE_STAMPS
-#define MMFE_STAMP(i)                                                                                   \
-    do {                                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                              \
-        unsigned long long _t;                                                                          \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                      \
-        __builtin_amdgcn_sched_barrier(0);                                                              \
-        if ((i) > 0) st_acc[(i) - 1] += _t - st_prev;                                                   \
-        st_prev = _t;                                                                                   \
-    } while (0)
-#else
-#define MMFE_STAMP(i) do { } while (0)
-#endif
 
 // 5-point forward DFT in place.
 __device__ __forceinline__ void dft5(float2& x0, float2& x1, float2& x2, float2& x3, float2& x4) {
@@ -159,35 +129,18 @@ __device__ __forceinline__ void fft25(float2 (&z)[25]) {
     for (int c1 = 0; c1 < 5; ++c1) dft5(z[5 * c1], z[5 * c1 + 1], z[5 * c1 + 2], z[5 * c1 + 3], z[5 * c1 + 4]);   // c2 lands at z[5*c1 + c2]
 }
 
-// Position of staged sample i (relative to the wave's first sample) in the LDS staging buffer.  With
-// hop 160 the four frame pairs of a wave start 320 floats apart, i.e. on the same LDS banks; 16
-// floats of padding per 320 samples put them on four different bank groups.  A run of 16 samples
-// that starts at a multiple of 16 never straddles a padding gap.
-template <int HOP>
-__device__ __forceinline__ int stage_pos(int i) {
-    if constexpr (HOP == 160) return i + 16 * (i / 320);
-    else return i;
-}
-
-// Four consecutive samples as floats: one 16-byte load of floats, or one 8-byte load of 16-bit PCM decoded as s / 32768.
-__device__ __forceinline__ float4 load4(const float* sp) { return *reinterpret_cast<const float4*>(sp); }
-__device__ __forceinline__ float4 load4(const int16_t* sp) {
-    const uint2 r = *reinterpret_cast<const uint2*>(sp);
-    constexpr float k = 1.0f / 32768.0f;
-    return make_float4((float)(int16_t)(r.x & 0xffffu) * k, (float)((int32_t)r.x >> 16) * k,
-                       (float)(int16_t)(r.y & 0xffffu) * k, (float)((int32_t)r.y >> 16) * k);
-}
-
-// Stored element i of a row of n under the plan's padding rule (i may lie outside the row), undecoded.
+// Stored element i of a row of n >= 1 under the plan's padding rule (i may lie outside the row), undecoded.  Straight-line code (an
+// index that always lies inside the row, then a select): with a branch per sample the 50 calls of an edge octet turn into 50 small
+// basic blocks whose loaded values the register allocator parks in scratch.
 template <typename S>
 __device__ __forceinline__ S fetch_raw(const S* row, int i, int n, int pad_mode) {
-    if (i >= 0 && i < n) return row[i];
-    if (n <= 0 || pad_mode != MMFE_PAD_REFLECT) return S(0);
-    if (n == 1) return row[0];
-    const int period = 2 * (n - 1);
+    const int period = n > 1 ? 2 * (n - 1) : 1;
     int m = i % period;
-    if (m < 0) m += period;
-    return row[m < n ? m : period - m];
+    m = m < 0 ? m + period : m;
+    m = m < n ? m : period - m;                       // the reflected position
+    const bool inside = i >= 0 && i < n;
+    const S v = row[inside ? i : m];
+    return (inside || pad_mode == MMFE_PAD_REFLECT) ? v : S(0);
 }
 
 // One output element / four consecutive ones in the plan's output type; `i` counts elements.
@@ -200,69 +153,79 @@ __device__ __forceinline__ void store4(const Rfft400Args& p, int64_t i, float a,
     else *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + i) = make_uint2(pack2_bits(a, b, p.out_dtype), pack2_bits(c, d, p.out_dtype));
 }
 
-template <typename SMP /* input element: float or int16_t PCM */, int HOP /* 160: the two frames of a pair share their loads (and the staging layout of the LDS-staged form is specialised); 0: any hop <= 160 */,
-          bool VEC /* row starts aligned to 4 samples and hop % 4 == 0 */,
+// LDS of a block: twiddles | window | mel weights | one work area per wave.
+//   work area of a wave: 4 pairs x kPairBytes.  Every phase of a pass reuses it:
+//     T1  rows c = 0..15 of the pair's 25 x 16 transpose tile (16 rows x 128 bytes), T2 rows 16..24 in the same place once T1 has been
+//         read (the tile in two shots: 2 KB per pair instead of 3.2 KB is what lets a third wave per SIMD fit the CU's LDS);
+//         row r keeps its 16-byte column pairs XOR-swizzled by (r >> 1) & 7, so that the 16 rows one 16-byte read touches fall on 16
+//         distinct bank groups without padding the 128-byte row stride
+//     Z   the upper half of the spectrum, Z[200 .. 400], parked at index k - 200 for the partners of the bins k <= 200
+//     P   the 8 power spectra of the wave (kPS floats apart), operands of the matrix-pipe mel projection
+constexpr int kPairBytes = 2048;
+constexpr int kWaveBytes = 4 * kPairBytes;          // 8192
+constexpr int kWinStride = 28;                      // floats per lane in the LDS window table: 25 taps + 3; 16-byte reads of 16 lanes conflict-free
+constexpr int kWinBytes = 16 * kWinStride * 4;      // 1792
+
+// Floats per lane in the LDS mel-weight table: every stream's steps padded to a multiple of 4 (16-byte reads), and a stride whose
+// quarter is odd (the 16-byte reads of 16 consecutive lanes fall on distinct bank groups).
+constexpr int r400_pad4(int v) { return (v + 3) & ~3; }
+constexpr int r400_wstride(int s0, int s1, int s2, int s3) {
+    const int t = r400_pad4(s0) + r400_pad4(s1) + r400_pad4(s2) + r400_pad4(s3);
+    return (t / 4) % 2 == 1 ? t : t + 4;
+}
+
+template <typename SMP /* input element: float or int16_t PCM */, int HS /* hop / 16 when the hop is a multiple of 16 (at most 160), else 0 */,
           int S0, int S1, int S2, int S3 /* bins walked by the four mel instruction streams */, bool SPLIT /* last stream: runs split in two halves */>
-__global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Args p) {
+__global__ void __launch_bounds__(64 * kWaves, 3) rfft400_kernel(const Rfft400Args p) {
     constexpr int kSteps[kStreams] = {S0, S1, S2, S3};
-    constexpr int kStepOff[kStreams] = {0, S0, S0 + S1, S0 + S1 + S2};
-    constexpr int kTotalSteps = S0 + S1 + S2 + S3;
+    constexpr int kStepOff[kStreams] = {0, S0, S0 + S1, S0 + S1 + S2};                                        // in the step-major device table
+    constexpr int kLdsOff[kStreams] = {0, r400_pad4(S0), r400_pad4(S0) + r400_pad4(S1), r400_pad4(S0) + r400_pad4(S1) + r400_pad4(S2)};
+    constexpr int kWStride = r400_wstride(S0, S1, S2, S3);
     constexpr int kLastStream = S3 > 0 ? 3 : (S2 > 0 ? 2 : (S1 > 0 ? 1 : 0));
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* s_tw = reinterpret_cast<float2*>(smem);
+    float2* s_tw = reinterpret_cast<float2*>(smem);                                  // [25][16]: W400^(b*c)
+    float* s_win = reinterpret_cast<float*>(smem + kTwBytes);                        // [16][kWinStride]: window[16a + b] at [b][a]
+    float* s_w = reinterpret_cast<float*>(smem + kTwBytes + kWinBytes);              // [64][kWStride]: mel weights of lane l, stream by stream
     for (int i = threadIdx.x; i < 25 * 16; i += blockDim.x) s_tw[i] = p.tw[i];
+    for (int i = threadIdx.x; i < 16 * kWinStride; i += blockDim.x) {
+        const int bb = i / kWinStride, a = i - bb * kWinStride;
+        s_win[i] = a < 25 ? p.window[16 * a + bb] : 0.f;
+    }
+    for (int i = threadIdx.x; i < 64 * kWStride; i += blockDim.x) {
+        const int l = i / kWStride, o = i - l * kWStride;
+        float w = 0.f;
+#pragma unroll
+        for (int st = 0; st < kStreams; ++st)
+            if (kSteps[st] > 0 && o >= kLdsOff[st] && o < kLdsOff[st] + kSteps[st]) w = p.mel_w[(kStepOff[st] + o - kLdsOff[st]) * 64 + l];
+        s_w[i] = w;
+    }
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pr = lane >> 4;      // frame pair within the wave
-    const int b = lane & 15;       // lane within the pair's group
-    char* wave_area = smem + kTwBytes + wave * kWaveBytes;
-#if !MMFE_R400_DIRECT
-    float* stage = reinterpret_cast<float*>(wave_area);
-#endif
-    float2* tile = reinterpret_cast<float2*>(wave_area + pr * kPairBytes);
-    float* parea = reinterpret_cast<float*>(wave_area);
+    char* const wave_area = smem + kTwBytes + kWinBytes + 64 * kWStride * 4 + wave * kWaveBytes;
+    float* const parea = reinterpret_cast<float*>(wave_area);
 
-    // Bin runs of the mel stage may read a few slots that no phase writes (tile padding, staging gaps) with
-    // zero weights; start from zeros so that those slots can never hold a non-finite bit pattern.
     for (int i = lane; i < kWaveBytes / 16; i += 64) reinterpret_cast<float4*>(wave_area)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     wave_lds_fence();
 
-    const int hop = HOP > 0 ? HOP : p.hop;
-#if !MMFE_R400_DIRECT
-    const int span4 = (7 * hop + kN + 3) & ~3;      // samples staged per pass, rounded up to whole 16-byte pieces
-#endif
-
-    // ---- per-lane constants, resident for the life of the kernel -----------------------------------
-    float win[25];
-#pragma unroll
-    for (int a = 0; a < 25; ++a) win[a] = p.window[16 * a + b];
-    float wreg[kTotalSteps];
-#pragma unroll
-    for (int s = 0; s < kTotalSteps; ++s) wreg[s] = p.mel_w[s * 64 + lane];
-    const float* pa[kStreams];
-    int dst[kStreams];
+    const int hop = p.hop;
+    // what a lane keeps across passes: where its mel operands start and which (filter, frame group) each stream leaves it with
+    int poff[kStreams], dst[kStreams];
 #pragma unroll
     for (int st = 0; st < kStreams; ++st) {
-        pa[st] = parea + (kSteps[st] > 0 ? p.mel_poff[st * 64 + lane] : 0);
+        poff[st] = kSteps[st] > 0 ? p.mel_poff[st * 64 + lane] : 0;
         dst[st] = kSteps[st] > 0 ? p.mel_dst[st * 64 + lane] : -1;
     }
-    // ---- work distribution: octet = 8 consecutive frames of one row; a block takes kWaves consecutive
-    //      octets per round, so its waves stream one contiguous region and fill whole output lines ------
+    // ---- work distribution: octet = 8 consecutive frames of one row; a block owns a contiguous range of rounds of kWaves consecutive
+    //      octets, so a wave stays inside a row for many passes (the per-row extremes of clamp_below_max are reduced once per row) ------
     const unsigned opr = (unsigned)(p.frames_valid + 7) >> 3;      // octets per row
-#if MMFE_R400_RANGES
-    // rounds of kWaves consecutive octets; block b owns rounds [b * per_block, (b + 1) * per_block)
     const unsigned n_rounds = ((unsigned)p.n_rows * opr + kWaves - 1) / kWaves;
     const unsigned per_block = (n_rounds + gridDim.x - 1) / gridDim.x;
     const unsigned round0 = blockIdx.x * per_block;
     unsigned rounds_left = round0 < n_rounds ? (n_rounds - round0 < per_block ? n_rounds - round0 : per_block) : 0;
     const unsigned ostride = kWaves;
     const unsigned oct0 = round0 * kWaves + wave;
-#else
-    const unsigned ostride = gridDim.x * kWaves;
-    const unsigned oct0 = blockIdx.x * kWaves + wave;
-#endif
     const unsigned d_row = ostride / opr, d_o = ostride - d_row * opr;
     unsigned row = oct0 / opr, oq = oct0 - row * opr;               // wave-uniform
     auto advance = [&](unsigned& r, unsigned& o) {
@@ -271,15 +234,14 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
         if (o >= opr) { o -= opr; r += 1; }
     };
 
-#if MMFE_R400_DIRECT
-    // the samples of the lane's two frames under octet (r, o): n = 16a + b of frame A = 2*pr and of frame B = A + 1
-    // (kept as loaded; 16-bit PCM is decoded where the values are used, so that nothing waits for the loads here).
-    // With a hop of 16 * HS (HOP = 160: HS = 10), frame B's sample a IS frame A's sample a + HS of the same lane: one run
-    // g[0 .. 24 + HS] serves both frames, 35 loads per lane and pass instead of 50 (-7.5 % on the whole call at hop 160).
-    constexpr int HS = HOP / 16;
+    // the samples of the lane's two frames under octet (r, o): n = 16a + b of frame A = 2*pr and of frame B = A + 1, straight from
+    // global memory one pass ahead (the 2.5x overlap of neighbouring frames is served by L1 / L2; kept as loaded, 16-bit PCM is decoded
+    // where the values are used, so that nothing waits for the loads here).  With a hop of 16 * HS, frame B's sample a IS frame A's
+    // sample a + HS of the same lane: one run g[0 .. 24 + HS] serves both frames (35 loads instead of 50 at hop 160).
     constexpr int kNG = HS > 0 ? 25 + HS : 50;
+    constexpr bool kEarlyFetch = HS > 0 && MMFE_R400_EARLY_FETCH != 0;
     SMP g[kNG];
-    auto fetch = [&](unsigned r, unsigned o) {
+    auto fetch = [&](unsigned r, unsigned o, int pr, int b) {
         const unsigned rr = r < (unsigned)p.n_rows ? r : 0;
         const SMP* rp = row_ptr_as<SMP>(p.src, rr);
         const int n_row = row_samples(p.src, rr, p.n_samples);
@@ -296,58 +258,21 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
 #pragma unroll
                 for (int a = 0; a < 25; ++a) { g[a] = qa[16 * a]; g[25 + a] = qb[16 * a]; }
             }
-        } else {    // the octet touches an end of the row: padding rule per sample
+        } else if (n_row > 0) {    // the octet touches an end of the row: padding rule per sample
 #pragma unroll
             for (int a = 0; a < (HS > 0 ? kNG : 25); ++a) {
                 g[a] = fetch_raw(rp, ia + 16 * a, n_row, p.pad_mode);
                 if (HS == 0) g[25 + a] = fetch_raw(rp, ia + hop + 16 * a, n_row, p.pad_mode);
+                __builtin_amdgcn_sched_barrier(0);      // one position at a time: interleaved, the index arithmetic of all of them needs more
+                                                        // registers than the pass has, and the values loaded first go to scratch
             }
+        } else {
+#pragma unroll
+            for (int a = 0; a < kNG; ++a) g[a] = SMP(0);
         }
     };
-    fetch(row, oq);
-#else
-    // the samples under octet (r, o): lane holds pieces lane, lane+64, ... of 4 consecutive samples
-    float4 pf[kPF];
-    auto fetch = [&](unsigned r, unsigned o) {
-        const unsigned rr = r < (unsigned)p.n_rows ? r : 0;
-        const SMP* rp = row_ptr_as<SMP>(p.src, rr);
-        const int n_row = row_samples(p.src, rr, p.n_samples);
-        const int first = (int)o * 8 * hop + p.shift;
-        const bool interior = first >= 0 && first + span4 <= n_row;     // wave-uniform
-        if (interior) {
-#pragma unroll
-            for (int q = 0; q < kPF; ++q) {
-                const int i = 4 * (lane + 64 * q);
-                const SMP* sp = rp + first + (i < span4 ? i : 0);
-                if (VEC) pf[q] = load4(sp);
-                else pf[q] = make_float4(sample_value(sp[0]), sample_value(sp[1]), sample_value(sp[2]), sample_value(sp[3]));
-            }
-        } else {    // the octet touches an end of the row: padding rule per sample
-#pragma unroll
-            for (int q = 0; q < kPF; ++q) {
-                const int i = 4 * (lane + 64 * q);
-                const int s0 = first + (i < span4 ? i : 0);
-                pf[q] = make_float4(fetch_sample(rp, s0, n_row, p.pad_mode), fetch_sample(rp, s0 + 1, n_row, p.pad_mode),
-                                    fetch_sample(rp, s0 + 2, n_row, p.pad_mode), fetch_sample(rp, s0 + 3, n_row, p.pad_mode));
-            }
-        }
-    };
-    fetch(row, oq);
+    fetch(row, oq, lane >> 4, lane & 15);
 
-    // sample n = 16a + b of frames A = 2*pr and B = 2*pr + 1 in the staging buffer
-    const float* st_a = stage + stage_pos<HOP>(2 * pr * hop) + b;
-    const float* st_b = HOP == 160 ? st_a + 160 : stage + (2 * pr + 1) * hop + b;
-#endif
-    float* const pw_a = parea + (2 * pr) * kPS + kPGuard;
-    float* const pw_b = pw_a + kPS;
-
-#ifdef MMFE_STAMPS
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
-#endif
-    // feature-major 16-byte stores: the lane's part of the address that does not change from pass to pass
-    int coff[kStreams];
-#pragma unroll
-    for (int st = 0; st < kStreams; ++st) coff[st] = dst[st] >= 0 ? (dst[st] & 0xffff) * p.out_frames + 4 * (dst[st] >> 16) : 0;
     float lmax = -INFINITY, lmin = INFINITY;      // running extremes of the row the wave is in (clamp_below_max plans)
     auto flush_extremes = [&](unsigned r) {
         const float wmax = wave_max(lmax), wmin = wave_min(lmin);
@@ -358,111 +283,132 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
         lmax = -INFINITY;
         lmin = INFINITY;
     };
-#if MMFE_R400_RANGES
     for (; rounds_left > 0 && row < (unsigned)p.n_rows; --rounds_left) {
-#else
-    while (row < (unsigned)p.n_rows) {
-#endif
-        MMFE_STAMP(0);
         const int t0 = (int)oq * 8;          // first frame of the octet
         const unsigned cur_row = row;
+        // Everything a lane derives from its number (tile addresses, swizzle keys, table rows) is recomputed per pass from a copy the
+        // optimiser cannot see through: kept across the loop these two dozen values cost more registers than the 168 a third wave
+        // per SIMD leaves, and went to scratch.
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int pr = l >> 4;         // frame pair within the wave
+        const int b = l & 15;          // lane within the pair's group
+        char* const area = wave_area + pr * kPairBytes;
+        float2* const zpark = reinterpret_cast<float2*>(area);
+        const int wr_col = 16 * (b >> 1) + 8 * (b & 1);               // byte offset of column b inside an unswizzled tile row
+        const int rd_row0 = 128 * b, rd_key0 = ((b >> 1) & 7) << 4;   // the row this lane reads in shot 1, and its swizzle key
+        const int b1 = b <= 8 ? b : 8;                                // shot 2 holds rows 16..24: lanes 9..15 repeat row 24, result unused
+        const int rd_row1 = 128 * b1, rd_key1 = ((b1 >> 1) & 7) << 4;
+        const float* const win_l = s_win + b * kWinStride;
+        const float* const w_l = s_w + l * kWStride;
+        // the slots of the spectrum area that no bin is written to (8 in front of the first frame, 15 behind every frame's bin 200):
+        // cleared every pass, because the area also serves as tile and parking space and the mel runs may touch them with zero weights
+        float* const gap0 = parea + (l < 8 ? l : kPGuard + (l >> 3) * kPS + 201 + (l & 7));
+        float* const gap1 = parea + kPGuard + (l >> 3) * kPS + (l < 8 ? 201 + l : 208 + (l & 7));
+        float* const pw_a = parea + (2 * pr) * kPS + kPGuard;
+        float* const pw_b = pw_a + kPS;
 
-#if MMFE_R400_DIRECT
         float2 z[25];
 #pragma unroll
-        for (int a = 0; a < 25; ++a) z[a] = make_float2(win[a] * sample_value(g[a]), win[a] * sample_value(g[HS > 0 ? a + HS : 25 + a]));
-#else
-        // ---- stage the wave's samples -----------------------------------------------------------
+        for (int j = 0; j < 7; ++j) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(win_l + 4 * j);
 #pragma unroll
-        for (int q = 0; q < kPF; ++q) {
-            const int i = 4 * (lane + 64 * q);
-            if (i < span4) *reinterpret_cast<float4*>(stage + stage_pos<HOP>(i)) = pf[q];
+            for (int e = 0; e < 4; ++e) {
+                const int a = 4 * j + e;
+                if (a < 25) z[a] = make_float2(w4[e] * sample_value(g[a]), w4[e] * sample_value(g[HS > 0 ? a + HS : 25 + a]));
+            }
         }
-        wave_lds_fence();
-        float2 z[25];
-#pragma unroll
-        for (int a = 0; a < 25; ++a) {
-            // hop 160: frame A crosses the padding gap at sample 320 of its pair (a >= 20), frame B at its sample 160 (a >= 10)
-            const int off_a = 16 * a + (HOP == 160 && a >= 20 ? 16 : 0);
-            const int off_b = 16 * a + (HOP == 160 && a >= 10 ? 16 : 0);
-            z[a] = make_float2(win[a] * st_a[off_a], win[a] * st_b[off_b]);
-        }
-        wave_lds_fence();
-
-#endif
-
-        MMFE_STAMP(1);
-        // ---- next octet's samples: in flight under the rest of this pass ----------------------------
-        advance(row, oq);
-        fetch(row, oq);
 
         // ---- 400-point complex FFT, first half: 25-point FFT over a, twiddle, transpose ------------
         fft25(z);
-        // The twiddle table and the tile are both LDS, and the compiler cannot tell them apart: a twiddle read
-        // placed after a tile write stays behind it and then costs a full LDS round trip before its product can be
-        // written.  So the reads run one group of MMFE_R400_TWGROUP ahead of the writes: 24 / group round trips instead of 24.
+        // The twiddle table and the tile are both LDS, and the compiler cannot tell them apart: a twiddle read placed after a tile
+        // write stays behind it and then costs a full LDS round trip before its product can be written.  So the reads run one group
+        // of 8 ahead of the writes.  Rows 0..15 go to the tile now (shot 1); rows 16..24 wait, twiddled, in registers.
         {
-            constexpr int G = MMFE_R400_TWGROUP;      // twiddles fetched per LDS round trip (24 = 3 x 8 = 6 x 4)
-            float2 tw_cur[G], tw_nxt[G];
+            float2 tw_cur[8], tw_nxt[8];
 #pragma unroll
-            for (int j = 0; j < G; ++j) tw_cur[j] = s_tw[(1 + j) * 16 + b];
-            tile[b] = z[fft25_pos(0)];
+            for (int j = 0; j < 8; ++j) tw_cur[j] = s_tw[(1 + j) * 16 + b];
+            *reinterpret_cast<float2*>(area + wr_col) = z[fft25_pos(0)];
 #pragma unroll
-            for (int g = 0; g < 24 / G; ++g) {
-                if (g + 1 < 24 / G) {
+            for (int g = 0; g < 3; ++g) {
+                if (g < 2) {
 #pragma unroll
-                    for (int j = 0; j < G; ++j) tw_nxt[j] = s_tw[(1 + G * (g + 1) + j) * 16 + b];
+                    for (int j = 0; j < 8; ++j) tw_nxt[j] = s_tw[(9 + 8 * g + j) * 16 + b];
                 }
 #pragma unroll
-                for (int j = 0; j < G; ++j) {
-                    const int c = 1 + G * g + j;
-                    tile[c * kTileStride + b] = cmul(z[fft25_pos(c)], tw_cur[j]);
+                for (int j = 0; j < 8; ++j) {
+                    const int c = 1 + 8 * g + j;
+                    const float2 v = cmul(z[fft25_pos(c)], tw_cur[j]);
+                    if (c < 16) *reinterpret_cast<float2*>(area + 128 * c + (wr_col ^ (((c >> 1) & 7) << 4))) = v;
+                    else z[fft25_pos(c)] = v;
                 }
 #pragma unroll
-                for (int j = 0; j < G; ++j) tw_cur[j] = tw_nxt[j];
+                for (int j = 0; j < 8; ++j) tw_cur[j] = tw_nxt[j];
             }
         }
+        if (kEarlyFetch) {
+            advance(row, oq);
+            fetch(row, oq, pr, b);
+        }
         wave_lds_fence();
-        MMFE_STAMP(2);
         float2 u0[16], u1[16];
-        {
-            const float2* r0 = tile + b * kTileStride;
-            const float2* r1 = tile + (b <= 8 ? 16 + b : 24) * kTileStride;     // lanes 9..15 repeat column 24, result unused
 #pragma unroll
-            for (int bb = 0; bb < 16; ++bb) { u0[bb] = r0[bb]; u1[bb] = r1[bb]; }
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(area + rd_row0 + ((q << 4) ^ rd_key0));
+            u0[2 * q] = make_float2(v.x, v.y);
+            u0[2 * q + 1] = make_float2(v.z, v.w);
+        }
+        wave_lds_fence();
+        // shot 2: rows 16..24 into the same place
+#pragma unroll
+        for (int c = 16; c < 25; ++c) *reinterpret_cast<float2*>(area + 128 * (c - 16) + (wr_col ^ ((((c - 16) >> 1) & 7) << 4))) = z[fft25_pos(c)];
+        wave_lds_fence();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(area + rd_row1 + ((q << 4) ^ rd_key1));
+            u1[2 * q] = make_float2(v.x, v.y);
+            u1[2 * q + 1] = make_float2(v.z, v.w);
         }
         wave_lds_fence();
 
-        MMFE_STAMP(3);
-#if MMFE_R400_HALFPARK
         // ---- second half: 16-point FFTs of columns b and b+16 leave Z[c + 25 d] in registers.  The two real spectra separate
         //      from the pairs (k, 400 - k), k <= 200: the lane owns k = c + 25 d for d <= 7 (and k = 200 = column 0, d = 8); the
-        //      partners 400 - k > 200 are the d >= 8 half of some column, which is all that goes to LDS -------------------------
+        //      partners 400 - k >= 200 are the d >= 8 half of some column, which is all that goes to LDS, at index k - 200 -------
         fft16(u0);
+        __builtin_amdgcn_sched_barrier(0);      // one transform after the other: interleaved, their temporaries do not fit next to the prefetched samples
         fft16(u1);
 #pragma unroll
-        for (int d = 8; d < 16; ++d) tile[b + 25 * d] = u0[fft16_pos(d)];
+        for (int d = 8; d < 16; ++d) zpark[b + 25 * d - 200] = u0[fft16_pos(d)];
         if (b <= 8) {
 #pragma unroll
-            for (int d = 8; d < 16; ++d) tile[16 + b + 25 * d] = u1[fft16_pos(d)];
+            for (int d = 8; d < 16; ++d) zpark[16 + b + 25 * d - 200] = u1[fft16_pos(d)];
         }
-        if (b == 0) tile[400] = u0[fft16_pos(0)];      // k = 0 pairs with itself; k = 200 finds itself at 400 - 200 (written above)
+        if (b == 0) zpark[200] = u0[fft16_pos(0)];      // k = 0 pairs with itself (index 400 - 200); k = 200 finds itself at 200 - 200 (written above)
         wave_lds_fence();
 
-        MMFE_STAMP(4);
+        // ---- next octet's samples: requested here, with the last third of the pass to arrive (the spectra' separation, the mel projection,
+        //      the logarithms and the stores).  Earlier, the 50 values in flight do not fit next to the transforms' registers in the 168 a
+        //      third wave per SIMD leaves; the other two waves of the SIMD cover what is left of the wait.
+        if (!kEarlyFetch) {
+            advance(row, oq);
+            fetch(row, oq, pr, b);
+        }
         float p_a[17], p_b[17];
 #pragma unroll
         for (int i = 0; i < 17; ++i) {
             // i < 9: column b, d = i (d = 8 is bin 200 + b: a real bin for b = 0 only); i >= 9: column 16 + b, d = i - 9 (b <= 8 only)
             const int k = i < 9 ? b + 25 * i : 16 + b + 25 * (i - 9);
             const float2 zk = i < 9 ? u0[fft16_pos(i)] : u1[fft16_pos(i - 9)];
-            const float2 zm = tile[400 - k];
+            const int km = 200 - k;                                       // partner 400 - k, parked at (400 - k) - 200
+            const float2 zm = zpark[km < 0 ? 0 : km];                     // (k > 200: lanes whose value is never stored)
             const float2 E = make_float2(zk.x + zm.x, zk.y - zm.y);     // X_A[k]
             const float2 D = make_float2(zk.x - zm.x, zk.y + zm.y);     // i * X_B[k]
             p_a[i] = E.x * E.x + E.y * E.y;
             p_b[i] = D.x * D.x + D.y * D.y;
         }
         wave_lds_fence();
+        *gap0 = 0.f;
+        *gap1 = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             pw_a[b + 25 * i] = p_a[i];
@@ -480,50 +426,8 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
             }
         }
         wave_lds_fence();
-#else
-        // ---- second half: 16-point FFTs of columns b and b+16; Z[c + 25 d] parked in natural order ----
-        fft16(u0);
-        fft16(u1);
-#pragma unroll
-        for (int d = 0; d < 16; ++d) tile[b + 25 * d] = u0[fft16_pos(d)];
-        if (b <= 8) {
-#pragma unroll
-            for (int d = 0; d < 16; ++d) tile[16 + b + 25 * d] = u1[fft16_pos(d)];
-        }
-        wave_lds_fence();
 
-        MMFE_STAMP(4);
-        // ---- separate the two real spectra, power ------------------------------------------------
-        float p_a[13], p_b[13];
-#pragma unroll
-        for (int i = 0; i < 13; ++i) {
-            int k = b + 16 * i;
-            if (i == 12) k = k < 200 ? k : 200;
-            int km = 400 - k;
-            if (i == 0) km = k == 0 ? 0 : km;
-            const float2 zk = tile[k];
-            const float2 zm = tile[km];
-            const float2 E = make_float2(zk.x + zm.x, zk.y - zm.y);     // X_A[k]
-            const float2 D = make_float2(zk.x - zm.x, zk.y + zm.y);     // i * X_B[k]
-            p_a[i] = E.x * E.x + E.y * E.y;
-            p_b[i] = D.x * D.x + D.y * D.y;
-        }
-        wave_lds_fence();
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            pw_a[b + 16 * i] = p_a[i];
-            pw_b[b + 16 * i] = p_b[i];
-        }
-        if (b <= 8) {
-            pw_a[192 + b] = p_a[12];
-            pw_b[192 + b] = p_b[12];
-        }
-        wave_lds_fence();
-
-#endif
-
-        MMFE_STAMP(5);
-        // ---- banded mel on the matrix pipe, log, affine, store ---------------------------------------
+        // ---- banded mel on the matrix pipe (weights from the LDS table, four steps per 16-byte read), log, affine, store ------
         float v[4 * kStreams];
 #pragma unroll
         for (int st = 0; st < kStreams; ++st) {
@@ -531,8 +435,12 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
             if (kSteps[st] > 0) {
                 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < kSteps[st]; ++s)
-                    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(pa[st][s], wreg[kStepOff[st] + s], acc, 0, 0, 0);
+                for (int s4 = 0; s4 < kSteps[st]; s4 += 4) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(w_l + kLdsOff[st] + s4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (s4 + e < kSteps[st]) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(parea[poff[st] + s4 + e], w4[e], acc, 0, 0, 0);
+                }
                 if (SPLIT && st == kLastStream) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[i] += upper_half_value(acc[i]);      // blocks 8..15 hold the second halves of the runs
@@ -541,7 +449,6 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[4 * st + i] = acc[i];
         }
-        MMFE_STAMP(6);
         apply_log_affine_block(v, p.la);
         if (p.layout == MMFE_LAYOUT_FEAT_MAJOR && p.vec_store && t0 + 8 <= p.frames_valid) {
             // whole octet, 16-byte feature-major stores (the regular case): no per-frame predicates, one 64-bit scalar base per pass
@@ -549,12 +456,14 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
 #pragma unroll
             for (int st = 0; st < kStreams; ++st) {
                 if (kSteps[st] == 0) continue;
-                if (dst[st] >= 0) {
+                int d = dst[st];
+                asm volatile("" : "+v"(d));      // (the address arithmetic below stays inside the pass, see the note on `l` above)
+                if (d >= 0) {
                     if (p.rowmax != nullptr) {
                         lmax = fmaxf(fmaxf(lmax, v[4 * st]), fmaxf(v[4 * st + 1], fmaxf(v[4 * st + 2], v[4 * st + 3])));
                         lmin = fminf(fminf(lmin, v[4 * st]), fminf(v[4 * st + 1], fminf(v[4 * st + 2], v[4 * st + 3])));
                     }
-                    store4(p, obase + coff[st], v[4 * st], v[4 * st + 1], v[4 * st + 2], v[4 * st + 3]);
+                    store4(p, obase + ((d & 0xffff) * p.out_frames + 4 * (d >> 16)), v[4 * st], v[4 * st + 1], v[4 * st + 2], v[4 * st + 3]);
                 }
             }
         } else {
@@ -562,7 +471,8 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
             for (int st = 0; st < kStreams; ++st) {
                 if (kSteps[st] == 0) continue;
                 // lane = 4*blk + j holds filter j of the block's unit for its 4 frames in v[4*st .. 4*st+3]
-                const int d = dst[st];
+                int d = dst[st];
+                asm volatile("" : "+v"(d));
                 const int m = d & 0xffff;
                 const int tf = t0 + 4 * (d >> 16);          // first of the lane's 4 frames
                 if (d >= 0) {
@@ -591,21 +501,11 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
                 }
             }
         }
-        // the extremes go to memory when the wave leaves the row (with contiguous block ranges: once per row, not once per pass)
-        if (p.rowmax != nullptr && (row != cur_row || MMFE_R400_RANGES == 0)) flush_extremes(cur_row);
-        MMFE_STAMP(7);
-#ifdef MMFE_STAMPS
-        st_acc[7] += 1;
-#endif
+        // the extremes go to memory when the wave leaves the row (once per row, not once per pass)
+        if (p.rowmax != nullptr && row != cur_row) flush_extremes(cur_row);
         wave_lds_fence();
-#if MMFE_R400_RANGES
         if (p.rowmax != nullptr && row == cur_row && rounds_left == 1) flush_extremes(cur_row);     // the range ends inside this row
-#endif
     }
-#ifdef MMFE_STAMPS
-    if (lane == 0)
-        for (int i = 0; i < 8; ++i) p.stamps[((size_t)blockIdx.x * kWaves + wave) * 8 + i] = st_acc[i];
-#endif
 }
 
 // clamp_below_max on the finished features.  The affine map (x + shift) * scale with scale > 0 is monotone, so it
@@ -651,10 +551,10 @@ constexpr MelShape kShapes[] = {
     {{36, 32, 0, 0}, true},       // 40 bands
 };
 
-template <typename SMP, int HOP, bool VEC, int S0, int S1, int S2, int S3, bool SPLIT>
+template <typename SMP, int HS, int S0, int S1, int S2, int S3, bool SPLIT>
 int launch_variant(const Rfft400Args& a, int64_t octets, int max_blocks_per_cu /* tuning, 0 = no limit */, int* cus_out, hipStream_t stream) {
-    const void* fn = reinterpret_cast<const void*>(&rfft400_kernel<SMP, HOP, VEC, S0, S1, S2, S3, SPLIT>);
-    const size_t lds = kTwBytes + (size_t)kWaves * kWaveBytes;
+    const void* fn = reinterpret_cast<const void*>(&rfft400_kernel<SMP, HS, S0, S1, S2, S3, SPLIT>);
+    const size_t lds = kTwBytes + kWinBytes + (size_t)64 * r400_wstride(S0, S1, S2, S3) * 4 + (size_t)kWaves * kWaveBytes;
     int blocks_per_cu = 1, cus = 256;
     int rc = kernel_prepare(fn, 64 * kWaves, lds, &blocks_per_cu, &cus);
     if (rc) return rc;
@@ -662,31 +562,9 @@ int launch_variant(const Rfft400Args& a, int64_t octets, int max_blocks_per_cu /
     *cus_out = cus;
     const int64_t want = (octets + kWaves - 1) / kWaves;
     const int grid = (int)std::min<int64_t>(want, (int64_t)cus * std::max(1, blocks_per_cu));
-#ifdef MMFE_STAMPS
-    Rfft400Args ta = a;
-    const size_t n_st = (size_t)grid * kWaves * 8;
-    MMFE_HIP_CHECK(hipMalloc((void**)&ta.stamps, n_st * 8));
-    MMFE_HIP_CHECK(hipMemset(ta.stamps, 0, n_st * 8));
-    hipLaunchKernelGGL((rfft400_kernel<SMP, HOP, VEC, S0, S1, S2, S3, SPLIT>), dim3(grid), dim3(64 * kWaves), lds, stream, ta);
-    MMFE_HIP_CHECK(hipDeviceSynchronize());
-    std::vector<unsigned long long> h(n_st);
-    MMFE_HIP_CHECK(hipMemcpy(h.data(), ta.stamps, n_st * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(ta.stamps);
-    static int printed = 0;
-    if (printed++ < 2) {
-        double sum[8] = {0};
-        for (size_t w = 0; w < n_st / 8; ++w) for (int i = 0; i < 8; ++i) sum[i] += (double)h[w * 8 + i];
-        const char* names[7] = {"stage+gather", "prefetch+fft25+Twrite", "Tread", "fft16x2+Zwrite", "separate+Pwrite", "mel(mfma)", "log+store+extremes"};
-        double tot = 0; for (int i = 0; i < 7; ++i) tot += sum[i];
-        for (int i = 0; i < 7; ++i) fprintf(stderr, "[stamps] %-22s %8.1f ticks/iter  %5.1f%%\n", names[i], sum[i] / sum[7], 100.0 * sum[i] / tot);
-        fprintf(stderr, "[stamps] total %.1f ticks/iter, %.0f iterations\n", tot / sum[7], sum[7]);
-    }
-    return MMFE_OK;
-#else
-    hipLaunchKernelGGL((rfft400_kernel<SMP, HOP, VEC, S0, S1, S2, S3, SPLIT>), dim3(grid), dim3(64 * kWaves), lds, stream, a);
+    hipLaunchKernelGGL((rfft400_kernel<SMP, HS, S0, S1, S2, S3, SPLIT>), dim3(grid), dim3(64 * kWaves), lds, stream, a);
     MMFE_HIP_CHECK(hipGetLastError());
     return MMFE_OK;
-#endif
 }
 
 }  // namespace
@@ -878,33 +756,17 @@ int rfft400_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int64
         a.rowmin = a.rowmax + cs.capacity;
     }
     const bool pcm = s.in_dtype == MMFE_IN_S16;
-    [[maybe_unused]] const bool vec = s.hop % 4 == 0 && a.shift % 4 == 0 && src.offsets == nullptr && src.stride % 4 == 0 &&
-                     reinterpret_cast<uintptr_t>(src.base) % (pcm ? 8 : 16) == 0;
     int rc = MMFE_EINVAL;
     bool found = false;
-#if MMFE_R400_DIRECT
 #define MMFE_R400_SHAPE(IDX, A, B, C, D, SP)                                                                     \
     if (plan.r400_shape == IDX) {                                                                                \
         found = true;                                                                                            \
-        if (s.hop == 160) {                                                                                      \
-            if (pcm) rc = launch_variant<int16_t, 160, false, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream);                \
-            else rc = launch_variant<float, 160, false, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream);                      \
-        } else if (pcm) rc = launch_variant<int16_t, 0, false, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream);               \
-        else rc = launch_variant<float, 0, false, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream);                            \
+        if (s.hop == 160) {   /* the long-utterance configuration: frames 10 x 16 samples apart share their loads */                \
+            if (pcm) rc = launch_variant<int16_t, 10, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream); \
+            else rc = launch_variant<float, 10, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream);       \
+        } else if (pcm) rc = launch_variant<int16_t, 0, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream); \
+        else rc = launch_variant<float, 0, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream);   \
     }
-#else
-#define MMFE_R400_SHAPE(IDX, A, B, C, D, SP)                                                                     \
-    if (plan.r400_shape == IDX) {                                                                                \
-        found = true;                                                                                            \
-        if (pcm) {                                                                                               \
-            if (s.hop == 160 && vec) rc = launch_variant<int16_t, 160, true, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream);     \
-            else if (vec) rc = launch_variant<int16_t, 0, true, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream);                  \
-            else rc = launch_variant<int16_t, 0, false, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream);                          \
-        } else if (s.hop == 160 && vec) rc = launch_variant<float, 160, true, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream);    \
-        else if (vec) rc = launch_variant<float, 0, true, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream);                        \
-        else rc = launch_variant<float, 0, false, A, B, C, D, SP>(a, octets, plan.tune_blocks_per_cu, &cus, stream);                                \
-    }
-#endif
     MMFE_R400_SHAPE(0, 5, 19, 17, 0, true)
     MMFE_R400_SHAPE(1, 8, 20, 20, 0, true)
     MMFE_R400_SHAPE(2, 4, 8, 12, 24, false)
