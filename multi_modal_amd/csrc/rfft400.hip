@@ -40,7 +40,10 @@ namespace {
 
 constexpr int kN = 400;
 constexpr int kBins = 201;
-constexpr int kWaves = 4;                           // waves per block
+#ifndef MMFE_R400_WAVES
+#define MMFE_R400_WAVES 4
+#endif
+constexpr int kWaves = MMFE_R400_WAVES;             // waves per block
 constexpr int kMaxHop = 160;
 constexpr int kMaxSpan = 7 * kMaxHop + kN;          // samples under one wave pass: 1520
 [[maybe_unused]] constexpr int kPF = (kMaxSpan / 4 + 63) / 64;       // prefetch registers (16-byte) per lane: 6
@@ -70,6 +73,21 @@ constexpr int kStreams = 4;
 #define MMFE_R400_RANGES 1      // 1: a block works through one contiguous range of octets, so a wave stays inside a row for many passes and the
                                 //    per-row extremes of clamp_below_max are reduced across the wave once per row instead of once per pass.
                                 //    0: blocks take octets round-robin over the whole batch
+#endif
+
+#ifndef MMFE_R400_PIN
+#define MMFE_R400_PIN 1
+#endif
+#ifndef MMFE_R400_ROTATE
+#define MMFE_R400_ROTATE 1      // direct-load form: see "Rotated pass" in the kernel
+#endif
+#ifndef MMFE_R400_NTLOAD
+#define MMFE_R400_NTLOAD 0
+#endif
+#if MMFE_R400_NTLOAD
+#define MMFE_R400_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define MMFE_R400_LOAD(ptr) (*(ptr))
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -203,7 +221,7 @@ __device__ __forceinline__ void store4(const Rfft400Args& p, int64_t i, float a,
 template <typename SMP /* input element: float or int16_t PCM */, int HOP /* 160: the two frames of a pair share their loads (and the staging layout of the LDS-staged form is specialised); 0: any hop <= 160 */,
           bool VEC /* row starts aligned to 4 samples and hop % 4 == 0 */,
           int S0, int S1, int S2, int S3 /* bins walked by the four mel instruction streams */, bool SPLIT /* last stream: runs split in two halves */>
-__global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Args p) {
+__global__ void __launch_bounds__(64 * kWaves, 2 * kWaves / 4 > 2 ? 2 : 2) rfft400_kernel(const Rfft400Args p) {
     constexpr int kSteps[kStreams] = {S0, S1, S2, S3};
     constexpr int kStepOff[kStreams] = {0, S0, S0 + S1, S0 + S1 + S2};
     constexpr int kTotalSteps = S0 + S1 + S2 + S3;
@@ -290,7 +308,7 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
             const SMP* qa = rp + ia;
             if (HS > 0) {
 #pragma unroll
-                for (int a = 0; a < kNG; ++a) g[a] = qa[16 * a];
+                for (int a = 0; a < kNG; ++a) g[a] = MMFE_R400_LOAD(qa + 16 * a);
             } else {
                 const SMP* qb = qa + hop;
 #pragma unroll
@@ -358,6 +376,28 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
         lmax = -INFINITY;
         lmin = INFINITY;
     };
+#if MMFE_R400_DIRECT && MMFE_R400_ROTATE
+    // Rotated pass: the window products z of the octet a pass transforms are formed at the END of the pass before (from the samples
+    // requested a whole pass earlier), right in front of the request for the octet after it and in front of that pass's stores.  The
+    // one wait of a pass for global memory then stands where the loads it covers are a pass old and the previous stores long done;
+    // with the products at the top of a pass the same wait also covers the stores issued a moment before.
+    float2 z[25];
+    auto window_products = [&]() {
+#pragma unroll
+        for (int a = 0; a < 25; ++a) z[a] = make_float2(win[a] * sample_value(g[a]), win[a] * sample_value(g[HS > 0 ? a + HS : 25 + a]));
+        // pinned in front of the next request: left free, the optimiser sinks the products below it (towards their use), and because
+        // loads return in order the wait for the old samples becomes a wait for the new ones as well
+#pragma unroll
+        for (int a = 0; a < 25; ++a) asm volatile("" : "+v"(z[a].x), "+v"(z[a].y));
+    };
+    unsigned zrow = row, zoq = oq;          // the octet whose products are in z; (row, oq) is the octet whose samples are in flight
+    window_products();
+    advance(row, oq);
+    fetch(row, oq);
+    for (; rounds_left > 0 && zrow < (unsigned)p.n_rows; --rounds_left) {
+        const int t0 = (int)zoq * 8;          // first frame of the octet
+        const unsigned cur_row = zrow;
+#else
 #if MMFE_R400_RANGES
     for (; rounds_left > 0 && row < (unsigned)p.n_rows; --rounds_left) {
 #else
@@ -371,6 +411,14 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
         float2 z[25];
 #pragma unroll
         for (int a = 0; a < 25; ++a) z[a] = make_float2(win[a] * sample_value(g[a]), win[a] * sample_value(g[HS > 0 ? a + HS : 25 + a]));
+#if MMFE_R400_PIN
+        // The products are pinned HERE, in front of the request for the next octet's samples.  Left free, the optimiser sinks them below
+        // that request (towards their use in the transform): the first use of the samples loaded one pass ago then stands behind the new
+        // loads in program order, and because loads return in order the wait for the old ones becomes a wait for ALL of them - the
+        // "prefetch" is waited for right after it is issued, every pass.
+#pragma unroll
+        for (int a = 0; a < 25; ++a) asm volatile("" : "+v"(z[a].x), "+v"(z[a].y));
+#endif
 #else
         // ---- stage the wave's samples -----------------------------------------------------------
 #pragma unroll
@@ -396,6 +444,7 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
         advance(row, oq);
         fetch(row, oq);
 
+#endif
         // ---- 400-point complex FFT, first half: 25-point FFT over a, twiddle, transpose ------------
         fft25(z);
         // The twiddle table and the tile are both LDS, and the compiler cannot tell them apart: a twiddle read
@@ -542,6 +591,16 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
             for (int i = 0; i < 4; ++i) v[4 * st + i] = acc[i];
         }
         MMFE_STAMP(6);
+#if MMFE_R400_DIRECT && MMFE_R400_ROTATE
+        window_products();
+        zrow = row;
+        zoq = oq;
+        advance(row, oq);
+        fetch(row, oq);
+#define MMFE_R400_NEXT_ROW zrow
+#else
+#define MMFE_R400_NEXT_ROW row
+#endif
         apply_log_affine_block(v, p.la);
         if (p.layout == MMFE_LAYOUT_FEAT_MAJOR && p.vec_store && t0 + 8 <= p.frames_valid) {
             // whole octet, 16-byte feature-major stores (the regular case): no per-frame predicates, one 64-bit scalar base per pass
@@ -554,6 +613,9 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
                         lmax = fmaxf(fmaxf(lmax, v[4 * st]), fmaxf(v[4 * st + 1], fmaxf(v[4 * st + 2], v[4 * st + 3])));
                         lmin = fminf(fminf(lmin, v[4 * st]), fminf(v[4 * st + 1], fminf(v[4 * st + 2], v[4 * st + 3])));
                     }
+#ifdef MMFE_ABL_NOSTORE      // diagnostic build: what the output stores cost (the condition is never true, the values stay live)
+                    if (v[4 * st] == 123.456f && v[4 * st + 1] == 654.321f)
+#endif
                     store4(p, obase + coff[st], v[4 * st], v[4 * st + 1], v[4 * st + 2], v[4 * st + 3]);
                 }
             }
@@ -592,14 +654,14 @@ __global__ void __launch_bounds__(64 * kWaves, 2) rfft400_kernel(const Rfft400Ar
             }
         }
         // the extremes go to memory when the wave leaves the row (with contiguous block ranges: once per row, not once per pass)
-        if (p.rowmax != nullptr && (row != cur_row || MMFE_R400_RANGES == 0)) flush_extremes(cur_row);
+        if (p.rowmax != nullptr && (MMFE_R400_NEXT_ROW != cur_row || MMFE_R400_RANGES == 0)) flush_extremes(cur_row);
         MMFE_STAMP(7);
 #ifdef MMFE_STAMPS
         st_acc[7] += 1;
 #endif
         wave_lds_fence();
 #if MMFE_R400_RANGES
-        if (p.rowmax != nullptr && row == cur_row && rounds_left == 1) flush_extremes(cur_row);     // the range ends inside this row
+        if (p.rowmax != nullptr && MMFE_R400_NEXT_ROW == cur_row && rounds_left == 1) flush_extremes(cur_row);     // the range ends inside this row
 #endif
     }
 #ifdef MMFE_STAMPS
