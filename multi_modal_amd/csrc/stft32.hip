@@ -210,6 +210,9 @@ __global__ void __launch_bounds__(kMaxThreads) stft32_kernel(const StftArgs p) {
     }
 }
 
+#ifndef MMFE_STFT_STAGE_FIRST
+#define MMFE_STFT_STAGE_FIRST 1
+#endif
 constexpr int kWsPrefetch = 6;   // float4 registers per mover lane for the samples of the group after next
 
 // Wave-specialised form (rows packed back to back from a 16-byte aligned base, hop a multiple of 4, group output blocks 16-byte
@@ -313,6 +316,13 @@ __global__ void __launch_bounds__(kMaxThreads) stft32_ws_kernel(const StftArgs p
             // all in registers across the loop (a dozen values per lane, spilled to scratch at this block size); recomputed per step
             // they cost one multiply-high per piece.
             asm volatile("" : "+v"(ml));
+#if MMFE_STFT_STAGE_FIRST
+            // The samples requested one step ago are dropped into LDS and the next request goes out BEFORE the previous image is stored:
+            // loads and stores return in order, so the wait for the samples would otherwise also be a wait for stores issued a moment
+            // before it; in this order everything that wait covers is a whole step old.
+            stage(grp + gridDim.x, s_in0 + ((t + 1) & 1) * in_floats);
+            fetch(grp + 2 * gridDim.x);
+#endif
             if (t > 0) {                                              // store the previous group's image
                 const int prev = grp - (int)gridDim.x;
                 const int rows = min(R, p.n_rows - prev * R);
@@ -337,8 +347,10 @@ __global__ void __launch_bounds__(kMaxThreads) stft32_ws_kernel(const StftArgs p
                 for (; i < n4; i += n_mover) { if (NT) __builtin_nontemporal_store(l4[i], g4 + i); else g4[i] = l4[i]; }
                 for (int j = 4 * n4 + ml; j < n_out; j += n_mover) gout[j] = s_out[j];
             }
+#if !MMFE_STFT_STAGE_FIRST
             stage(grp + gridDim.x, s_in0 + ((t + 1) & 1) * in_floats);
             fetch(grp + 2 * gridDim.x);
+#endif
         }
         lds_barrier();
     }
