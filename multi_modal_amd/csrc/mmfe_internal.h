@@ -144,7 +144,8 @@ struct Plan {
     int tune_chunk = 0;               // n_fft 512 kernel: consecutive frame quads a wave takes per visit; STFT-32 kernel: mover waves (-1: phase-serial form)
     int tune_nt = 1;                  // STFT-32 kernel: output stores bypass the caches
     // resampler, wave-uniform-phase kernel (rs_L == 0: not applicable, the general kernel serves the plan)
-    int rs_q = 4, rs_L = 0, rs_D = 0, rs_nb = 0, rs_groups = 0, rs_wlen = 0, rs_tile_in = 0, rs_ls = 0, rs_threads = 0;
+    int rs_q = 4, rs_L = 0, rs_D = 0, rs_nb = 0, rs_groups = 0, rs_wlen = 0, rs_wchunks = 0, rs_tile_in = 0, rs_lds_in = 0, rs_pad = 0, rs_round_out = 0,
+        rs_ls = 0, rs_threads = 0;
     // the same for 16-bit PCM rows, two blocks per CU (rs16_threads == 0: not applicable)
     int rs16_q = 0, rs16_L = 0, rs16_D = 0, rs16_groups = 0, rs16_wlen = 0, rs16_tile_in = 0, rs16_ls = 0, rs16_threads = 0, rs16_round_out = 0;
     int impl = 0;                     // which kernel family serves this plan

@@ -108,6 +108,9 @@ __global__ void __launch_bounds__(kThreads) resample_kernel(const ResampleArgs p
 
 
 // ---- wave-uniform-phase kernel --------------------------------------------------------------------------------------
+#ifndef MMFE_RS_LOAD_ALL
+#define MMFE_RS_LOAD_ALL 0      // 1: every thread requests all its pieces of the next tile, staged or not (A/B builds)
+#endif
 constexpr int kMaxPhaseThreads = 1024;
 constexpr int kPhasePF = 36;             // samples of the next tile held per thread (9 four-sample pieces in the vector form)
 constexpr int kPhaseLdsBytes = 158 * 1024;
@@ -128,15 +131,27 @@ struct ResamplePhaseArgs {
     int D;                     // input samples between neighbouring lanes: L * down / up
     int nb;                    // lane blocks (64 lanes each) per tile
     int groups;                // L / Q: runs of Q consecutive outputs inside L
-    int wlen;                  // window samples walked per run (a multiple of 8)
+    int wlen;                  // samples staged in front of a tile's first lane: the longest window of any run (a multiple of 8)
+    int wchunks;               // eight-sample chunks per run in the weight table (the longest run's count)
     int tile_in;               // staged input samples per tile
+    int lds_in;                // floats of LDS they take (tile_in, plus one per D samples when padded)
+    int pad;                   // 1: one unused float follows every D staged samples, see below
+    unsigned inv_D;            // ceil(2^32 / D): (k * inv_D) >> 32 == k / D for every staged index k
     int tile_out;              // nb * 64 * L
-    int ls;                    // floats between the output runs of neighbouring lanes in LDS (L, padded: a multiple of 4 whose quarter is odd)
+    int ls;                    // floats between the output runs of neighbouring lanes in LDS (padded so that 64 lanes fall on distinct banks)
+    int round_out;             // 0: a tile's outputs are collected whole.  Else: outputs of a lane per round of the block's waves (waves * Q),
+                               // stored round by round (one lane block per tile)
     int tiles_per_row;
     int vec_out;               // output rows start 16-byte aligned: whole tiles are stored 16 bytes per lane
-    const float* wt;           // [groups][wlen / 8][Q][8]: weight of window sample s for output q of the run, zero outside its taps
-    const int* gi;             // [groups]: input offset of window sample 0 of the run
+    const float* wt;           // [groups][wchunks][Q][8]: weight of window position s for output q of the run, zero outside its taps
+    const int* gi;             // [groups]: LDS offset of window position 0 of lane 0's run;  [groups]: chunks of the run
 };
+// Padded staging.  The lanes of a wave read LDS D floats apart; an even D puts them on a few of the 32 banks (D = 160, the 16 kHz ->
+// 44.1 kHz ratio: all 32 lanes of a half on ONE bank, every read serialised 32 times).  With pad = 1 staged sample k sits at
+// k + k / D, so the lane stride is D + 1, odd, conflict-free.  A run's window then walks over the unused floats where it crosses a
+// multiple of D; since all lanes start a whole number of D apart they cross at the same window position, and the host gives that
+// position a zero weight: the multiply-add loop is the same, its window one position longer per crossing.  The unused floats are
+// zeroed once per block (a zero weight times whatever LDS held could be NaN).
 
 // four consecutive samples as they lie in memory
 template <typename SMP> struct Piece;
@@ -159,18 +174,18 @@ template <> struct Piece<int16_t> {
 template <typename SMP, int Q, bool VEC>
 __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const ResamplePhaseArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* s_x = reinterpret_cast<float*>(smem);                       // tile_in (rounded up to 4)
-    float* s_o = s_x + ((p.tile_in + 3) & ~3);                         // nb * 64 * ls
+    float* s_x = reinterpret_cast<float*>(smem);                       // lds_in (rounded up to 4)
+    float* s_o = s_x + ((p.lds_in + 3) & ~3);                          // nb * 64 * ls, or 64 * ls of one round
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_waves = blockDim.x >> 6;
     const unsigned n_tiles = (unsigned)p.n_rows * (unsigned)p.tiles_per_row;      // < 2^31 (checked by the launcher)
-    const int chunks = p.wlen >> 3;
     typedef typename Piece<SMP>::type piece_t;
     constexpr int kPieces = kPhasePF / 4;
 
     SMP pf[VEC ? 1 : kPhasePF];
     piece_t pv[VEC ? kPieces : 1];
+    const int last_piece = (p.tile_in - 1) & ~3;                     // staged index of the tile's last four-sample piece
     // tile -> (row, first output); staged sample k of a tile is input sample lo + k of the row
     auto fetch = [&](unsigned tile) {
         if (tile >= n_tiles) return;
@@ -184,9 +199,14 @@ __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const 
         if (VEC) {
 #pragma unroll
             for (int q = 0; q < kPieces; ++q) {
-                const int g = lo + 4 * ((int)threadIdx.x + q * (int)blockDim.x);
+                // The block's threads cover 36 samples each, a tile may stage a third of that: a piece beyond the staged range re-reads
+                // the tile's last piece (one address per wave, a cache hit) instead of pulling the next tiles' samples from memory.
+                // (Skipping those loads under a branch instead serialises all nine: the wait-count pass cannot see that the branch
+                // around a load and the branch around its use go the same way, and waits for each load before issuing the next.)
+                const int k = MMFE_RS_LOAD_ALL ? 4 * ((int)threadIdx.x + q * (int)blockDim.x) : min(4 * ((int)threadIdx.x + q * (int)blockDim.x), last_piece);
+                const int g = lo + k;
                 // non-temporal: the input streams through once; cached, it pushes the filter weights out of L2 and every scalar-cache
-                // miss of the multiply-add loop then goes to memory (float32 input: 0.86 ms per 1024 clips cached, 0.66 non-temporal)
+                // miss of the multiply-add loop then goes to memory (float32 input: 0.86 ms per 1024 clips cached, 0.66 non-temporal).
                 pv[q] = __builtin_nontemporal_load(reinterpret_cast<const piece_t*>(x + (g < 0 ? 0 : (g + 4 <= n_row ? g : n_row - 4))));
             }
             return;
@@ -198,25 +218,10 @@ __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const 
         }
 #pragma unroll
         for (int q = 0; q < kPhasePF; ++q) {
-            const int g = lo + (int)threadIdx.x + q * (int)blockDim.x;
+            const int k = min((int)threadIdx.x + q * (int)blockDim.x, p.tile_in - 1);
+            const int g = lo + k;
             pf[q] = __builtin_nontemporal_load(x + (g < 0 ? 0 : (g < n_row ? g : n_row - 1)));
         }
-    };
-    // the same, one piece at a time (VEC): `next_begin` sets the row pointer and range of the tile, `next_piece(q)` requests piece q
-    const SMP* nx = nullptr;
-    int nlo = 0, nrow = 0;
-    auto next_begin = [&](unsigned tile) {
-        const unsigned t = tile < n_tiles ? tile : 0;                   // (beyond the batch: tile 0 is read and never staged)
-        const unsigned row = t / (unsigned)p.tiles_per_row;
-        const int m0 = (int)(t - row * (unsigned)p.tiles_per_row) * p.tile_out;
-        nlo = (m0 / p.up) * p.down - p.wlen;
-        nx = row_ptr_as<SMP>(p.src, row);
-        nrow = row_samples(p.src, row, p.n_in);
-    };
-    auto next_piece = [&](auto q_tag) {
-        constexpr int q = decltype(q_tag)::value;
-        const int g = nlo + 4 * ((int)threadIdx.x + q * (int)blockDim.x);
-        pv[VEC ? q : 0] = __builtin_nontemporal_load(reinterpret_cast<const piece_t*>(nx + (g < 0 ? 0 : (g + 4 <= nrow ? g : nrow - 4))));
     };
     // ---- drain: lane run j holds outputs m0 + j * L .. + L - 1 of `row` ----
     auto drain = [&](unsigned row, int m0) {
@@ -242,12 +247,34 @@ __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const 
             }
         }
     };
+    // ---- the outputs of one round (round_out > 0): lane run j holds outputs m0 + j * L + r * round_out .. + round_out - 1 ----
+    auto drain_round = [&](unsigned row, int m0, int r) {
+        float* orow = p.out + (int64_t)row * p.out_stride + m0;
+        const int n_valid = min(p.round_out, p.L - r * p.round_out);      // (the last round of a lane run may be short)
+        if (p.vec_out && m0 + p.tile_out <= p.n_out && (n_valid & 3) == 0 && (p.round_out & 3) == 0) {
+            const int r4 = n_valid >> 2;                                  // 16-byte pieces per lane run
+            for (int i = threadIdx.x; i < 64 * r4; i += blockDim.x) {
+                const int j = i / r4, k = i - j * r4;
+                __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(s_o + j * p.ls + 4 * k),
+                                            reinterpret_cast<f32x4*>(orow + (int64_t)j * p.L + r * p.round_out) + k);
+            }
+        } else {
+            for (int i = threadIdx.x; i < 64 * n_valid; i += blockDim.x) {
+                const int j = i / n_valid, k = i - j * n_valid;
+                const int64_t m = (int64_t)j * p.L + r * p.round_out + k;
+                if (m0 + m < p.n_out) __builtin_nontemporal_store(s_o[j * p.ls + k], orow + m);
+            }
+        }
+    };
 #ifdef MMFE_RS_STAMPS
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = 0, st_now = 0;
 #define RS_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory"); __builtin_amdgcn_sched_barrier(0); if ((i) >= 0) st_acc[(i)] += st_now - st_prev; st_prev = st_now; } while (0)
 #else
 #define RS_STAMP(i) do { } while (0)
 #endif
+    if (p.pad) {                                                        // the unused floats, once: staging never writes them
+        for (int j = threadIdx.x; j * (p.D + 1) + p.D < p.lds_in; j += blockDim.x) s_x[j * (p.D + 1) + p.D] = 0.f;
+    }
     fetch(blockIdx.x);
     for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         RS_STAMP(-1);
@@ -258,20 +285,31 @@ __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const 
         {
             const int lo = (m0 / p.up) * p.down - p.wlen;
             const int n_row = row_samples(p.src, row, p.n_in);
+            // (a thread's LDS positions are the same in every tile; left visible, the optimiser keeps all of them in registers across
+            // the loop - 36 per thread in the padded layout - and spills)
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
             if (VEC) {
 #pragma unroll
                 for (int q = 0; q < kPieces; ++q) {
-                    const int k = 4 * ((int)threadIdx.x + q * (int)blockDim.x);
+                    const int k = 4 * (tid + q * (int)blockDim.x);
                     const int g = lo + k;
-                    const f32x4 v = Piece<SMP>::decode(pv[q]);
-                    if (k < p.tile_in) *reinterpret_cast<f32x4*>(s_x + k) = (g >= 0 && g + 4 <= n_row) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const f32x4 v = (g >= 0 && g + 4 <= n_row) ? Piece<SMP>::decode(pv[q]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (k < p.tile_in) {
+                        if (!p.pad) {
+                            *reinterpret_cast<f32x4*>(s_x + k) = v;
+                        } else {                                      // (lds_in has room for the whole last piece)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) s_x[k + i + (int)__umulhi((unsigned)(k + i), p.inv_D)] = v[i];
+                        }
+                    }
                 }
             } else {
 #pragma unroll
                 for (int q = 0; q < kPhasePF; ++q) {
-                    const int k = threadIdx.x + q * blockDim.x;
+                    const int k = tid + q * (int)blockDim.x;
                     const int g = lo + k;
-                    if (k < p.tile_in) s_x[k] = (g >= 0 && g < n_row) ? sample_value(pf[q]) : 0.f;
+                    if (k < p.tile_in) s_x[p.pad ? k + (int)__umulhi((unsigned)k, p.inv_D) : k] = (g >= 0 && g < n_row) ? sample_value(pf[q]) : 0.f;
                 }
             }
         }
@@ -280,77 +318,71 @@ __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const 
         RS_STAMP(1);      // barrier after stage
         // The next tile's samples, requested here all at once.  s_memtime stamps (-DMMFE_RS_STAMPS) show the later waves of a block
         // sitting in the issue of these loads for up to 4 000 of a step's 24 000 cycles (16 waves x 9 loads pass the CU's 64 B/clk
-        // path to L1 one after the other).  -DMMFE_RS_FETCH_SPREAD=1 has each wave request ONE piece per chunk of its first run
-        // instead (VEC only): the waiting moves into the runs and the step takes as long (16-bit rows +0.6 %, float32 rows +5 %).
-#ifndef MMFE_RS_FETCH_SPREAD
-#define MMFE_RS_FETCH_SPREAD 0
-#endif
-        constexpr bool kSpread = VEC && MMFE_RS_FETCH_SPREAD;
-        bool fetched = !kSpread;
-        if (!kSpread) fetch(tile + gridDim.x);
-        else next_begin(tile + gridDim.x);
+        // path to L1 one after the other).  Having each wave request one piece per chunk of its first run instead moves the waiting
+        // into the runs and the step takes as long (measured: 16-bit rows +0.6 %, float32 rows +5 %).
+        fetch(tile + gridDim.x);
         RS_STAMP(2);      // fetch issue
-        // ---- runs: (lane block, group) pairs spread over the waves ----
-        for (int task = wave; task < p.nb * p.groups; task += n_waves) {
-            const int blk = task / p.groups;
-            const int u = task - blk * p.groups;
-            const float* xl = s_x + p.wlen + (blk * 64 + lane) * p.D + ((const_int*)p.gi)[u];
+        // ---- runs: (lane block, group) pairs spread over the waves.  Every wave takes the same number of turns (rounds end in
+        //      barriers when the outputs leave round by round); a turn beyond the last run is empty. ----
+        const int n_tasks = p.nb * p.groups;
+        for (int t0 = 0, r = 0; t0 < n_tasks; t0 += n_waves, ++r) {
+            const int task = t0 + wave;
+            if (task < n_tasks) {
+                const int blk = task / p.groups;
+                const int u = task - blk * p.groups;
+                const float* xl = s_x + (blk * 64 + lane) * (p.D + p.pad) + ((const_int*)p.gi)[u];
+                const int chunks = ((const_int*)p.gi)[p.groups + u];
 #ifdef MMFE_RS_ABL_SAMEW      // diagnostic build: every run reads group 0's weights (wrong results; shows what scalar-cache misses cost)
-            const_f32x8* w = ((const_f32x8*)p.wt);
+                const_f32x8* w = ((const_f32x8*)p.wt);
 #else
-            const_f32x8* w = ((const_f32x8*)p.wt) + (int64_t)u * chunks * Q;
+                const_f32x8* w = ((const_f32x8*)p.wt) + (int64_t)u * p.wchunks * Q;
 #endif
-            float acc[Q];
+                float acc[Q];
 #pragma unroll
-            for (int q = 0; q < Q; ++q) acc[q] = 0.f;
-            // (requesting the next chunk's weights and samples ahead of the multiply-adds, in a second register set, measured 3 %
-            // slower: scalar loads and LDS reads share one counter and scalar loads return out of order, so any wait is a wait for
-            // everything, and the other waves of the SIMD already fill the gaps)
-            // (skipping, in the window's first and last chunks, the outputs that have no taps there - 13 % of the multiply-adds - measured
-            // 5 to 23 % slower: the wave-uniform branches cost the loop its overlap of loads and arithmetic)
-            auto chunk = [&](int c) {
-                f32x8 wq[Q];
+                for (int q = 0; q < Q; ++q) acc[q] = 0.f;
+                // (requesting the next chunk's weights and samples ahead of the multiply-adds, in a second register set, measured 3 %
+                // slower: scalar loads and LDS reads share one counter and scalar loads return out of order, so any wait is a wait for
+                // everything, and the other waves of the SIMD already fill the gaps)
+                // (skipping, in the window's first and last chunks, the outputs that have no taps there - 13 % of the multiply-adds - measured
+                // 5 to 23 % slower: the wave-uniform branches cost the loop its overlap of loads and arithmetic)
+                for (int c = 0; c < chunks; ++c) {
+                    f32x8 wq[Q];
 #pragma unroll
-                for (int q = 0; q < Q; ++q) wq[q] = w[c * Q + q];
+                    for (int q = 0; q < Q; ++q) wq[q] = w[c * Q + q];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float xv = xl[-(c * 8 + e)];
+                    for (int e = 0; e < 8; ++e) {
+                        const float xv = xl[-(c * 8 + e)];
 #pragma unroll
-                    for (int q = 0; q < Q; ++q) acc[q] = fmaf(wq[q][e], xv, acc[q]);
+                        for (int q = 0; q < Q; ++q) acc[q] = fmaf(wq[q][e], xv, acc[q]);
+                    }
                 }
-            };
-            int c = 0;
-            if (kSpread && !fetched) {                                  // the wave's first run of the tile: chunk q also requests piece q
-                auto step = [&](auto q_tag) {
-                    next_piece(q_tag);
-                    if (decltype(q_tag)::value < chunks) chunk(decltype(q_tag)::value);
-                };
-                step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
-                step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
-                step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
-                static_assert(kPieces == 9, "one step per piece");
-                c = kPieces < chunks ? kPieces : chunks;
-                fetched = true;
-            }
-            for (; c < chunks; ++c) chunk(c);
-            float* so = s_o + (blk * 64 + lane) * p.ls + Q * u;
-            if (Q == 4) {
-                *reinterpret_cast<f32x4*>(so) = f32x4{acc[0], acc[1], acc[2], acc[3]};
-            } else {
+                float* so = p.round_out > 0 ? s_o + lane * p.ls + Q * wave : s_o + (blk * 64 + lane) * p.ls + Q * u;
+                if (Q == 4) {
+                    *reinterpret_cast<f32x4*>(so) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+                } else {
 #pragma unroll
-                for (int q = 0; q < Q; ++q) so[q] = acc[q];
+                    for (int q = 0; q < Q; ++q) so[q] = acc[q];
+                }
+            }
+            if (p.round_out > 0) {
+                lds_barrier();
+                drain_round(row, m0, r);
+                // the output area is written again at the end of the next round's runs; the last round needs no barrier here: the
+                // barrier behind the next tile's stage stands between these reads and those writes
+                if (t0 + n_waves < n_tasks) lds_barrier();
             }
         }
-        if (!fetched) fetch(tile + gridDim.x);                          // (a wave without a run in this tile)
         RS_STAMP(3);      // runs
-        lds_barrier();
-        RS_STAMP(4);      // barrier after runs
-        // (storing a tile's outputs one step later instead - after the next tile is staged and before its samples' successors are
-        // requested, so that no stage ever waits behind stores - measured 6 % (16-bit input) to 16 % (float32) slower)
-        drain(row, m0);
-        RS_STAMP(5);      // drain
-        // (no barrier here: the next step's stage only writes s_x, whose readers passed the barrier above, and s_o is not written
-        // again before the barrier that follows the stage)
+        if (p.round_out == 0) {
+            lds_barrier();
+            RS_STAMP(4);      // barrier after runs
+            // (storing a tile's outputs one step later instead - after the next tile is staged and before its samples' successors are
+            // requested, so that no stage ever waits behind stores - measured 6 % (16-bit input) to 16 % (float32) slower)
+            drain(row, m0);
+            RS_STAMP(5);      // drain
+            // (no barrier here: the next step's stage only writes s_x, whose readers passed the barrier above, and s_o is not written
+            // again before the barrier that follows the stage)
+        }
     }
 #ifdef MMFE_RS_STAMPS
     if (blockIdx.x == 3 && lane == 0 && (wave == 0 || wave == 9))
@@ -387,6 +419,7 @@ __global__ void __launch_bounds__(kMaxPhaseThreads, 8) resample_phase16_kernel(c
     const int chunks = p.wlen >> 3;
     constexpr int kPieces = kPhasePF / 4;
     u32x2 pv[kPieces];
+    const int last_piece = (p.tile_in - 1) & ~3;
     // -DMMFE_RS16_INTERIOR=1: tiles whose staged range lies inside the row (all but a row's first and last) take paths without
     // per-piece tests.  Fewer instructions, but at this kernel's 64-register cap the second code path costs more scalar-register
     // spills than the tests did: measured 1.3 % slower, so it is off.
@@ -408,7 +441,9 @@ __global__ void __launch_bounds__(kMaxPhaseThreads, 8) resample_phase16_kernel(c
         }
 #pragma unroll
         for (int q = 0; q < kPieces; ++q) {
-            const int g = lo + 4 * ((int)threadIdx.x + q * (int)blockDim.x);
+            // (a piece beyond the staged range re-reads the tile's last piece, see resample_phase_kernel)
+            const int k = MMFE_RS_LOAD_ALL ? 4 * ((int)threadIdx.x + q * (int)blockDim.x) : min(4 * ((int)threadIdx.x + q * (int)blockDim.x), last_piece);
+            const int g = lo + k;
             pv[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(x + (g < 0 ? 0 : (g + 4 <= p.n_in ? g : p.n_in - 4))));
         }
     };
@@ -532,7 +567,12 @@ int resample_prepare(Plan& plan) {
     const int pre = (half + pre_pad) / down;
     // Q = 4 or 5 consecutive outputs per lane: whichever fills the rounds of a block's waves better.  The multiply-adds of a
     // tile take `rounds` turns of (waves per SIMD) runs of wlen * Q each.
-    struct Layout { int Q = 0, L = 0, D = 0, groups = 0, wlen = 0, i_max = 0, nb = 0, threads = 0, tile_in = 0, ls = 0; double cost = 0; std::vector<int32_t> gi; std::vector<int> io, ph; };
+    struct Layout {
+        int Q = 0, L = 0, D = 0, groups = 0, wlen = 0, wchunks = 0, i_max = 0, nb = 0, threads = 0, tile_in = 0, lds_in = 0, ls = 0, pad = 0, round_out = 0;
+        double cost = 0;
+        std::vector<int32_t> table;      // [groups] LDS offset of window position 0, [groups] chunks
+        std::vector<int> io, ph, last;   // per output: newest input sample and phase;  per run: its newest input sample
+    };
     Layout best;
     // Q = 3 and 7 serve the odd `up` of upsampling ratios (441/160, 147/80, 3/1, 3/2: lanes `up` outputs apart leave whole runs of 3 or 7);
     // their lane runs are not whole 16-byte pieces, so those tiles are stored 4 bytes per lane (still contiguous rows)
@@ -546,9 +586,9 @@ int resample_prepare(Plan& plan) {
         c.L = (int)L;
         c.D = (int)(L * down / up);
         c.groups = (int)(L / Q);
-        c.gi.resize(c.groups);
         c.io.resize(c.groups * Q);
         c.ph.resize(c.groups * Q);
+        c.last.resize(c.groups);
         int max_back = 0;
         for (int u = 0; u < c.groups; ++u) {
             for (int q = 0; q < Q; ++q) {
@@ -556,41 +596,91 @@ int resample_prepare(Plan& plan) {
                 c.io[u * Q + q] = (int)(t / up);
                 c.ph[u * Q + q] = (int)(t % up);
             }
-            c.gi[u] = c.io[u * Q + Q - 1];
-            c.i_max = std::max(c.i_max, c.gi[u]);
-            max_back = std::max(max_back, c.gi[u] - c.io[u * Q]);
+            c.last[u] = c.io[u * Q + Q - 1];
+            c.i_max = std::max(c.i_max, c.last[u]);
+            max_back = std::max(max_back, c.last[u] - c.io[u * Q]);
         }
-        c.wlen = (taps + max_back + 7) & ~7;
+        // An even lane stride D puts the 32 lanes of a read on few banks: one unused float per D staged samples makes it odd.  Every
+        // unused float a window walks over is a chunk position without work, so a small D pays more than it gains (measured, 256
+        // clips: D = 2: 0.099 ms plain, 0.119 padded; D = 8: 0.210 / 0.219; D = 12: 0.251 / 0.202; D = 160: 0.325 / 0.096).
+        const char* force_pad = std::getenv("MMFE_RESAMPLE_PAD");      // tuning / test knob, read once per plan: 0 or 1
+        c.pad = c.D < 2 ? 0 : force_pad != nullptr ? (std::atoi(force_pad) != 0 ? 1 : 0) : (c.D % 2 == 0 && c.D > 8 ? 1 : 0);
+        // Samples staged in front of lane 0's first run.  A run reads whole chunks of 8 LDS floats downwards from its newest sample:
+        // at most taps + max_back samples, the unused floats among them, and up to 7 floats of the last chunk's rounding.
+        const int crossings = c.pad ? (taps + max_back) / c.D + 1 : 0;
+        c.wlen = (taps + max_back + crossings + 6 + 7) & ~7;
+        auto lds_pos = [&](int64_t k) { return k + (c.pad ? k / c.D : 0); };
+        // per run: LDS offset of its window position 0 (lane 0) and its chunk count; position s of the window is the float s below
+        c.table.resize(2 * c.groups);
+        int64_t fma_chunks = 0;
+        for (int u = 0; u < c.groups; ++u) {
+            const int64_t top = c.wlen + c.last[u];                               // staged index of the run's newest sample (lane 0)
+            const int64_t bottom = top - (taps - 1 + c.last[u] - c.io[u * Q]);     // ... and of its oldest (>= 0: wlen covers the longest window)
+            const int n_pos = (int)(lds_pos(top) - lds_pos(bottom)) + 1;
+            c.table[u] = (int32_t)lds_pos(top);
+            c.table[c.groups + u] = (n_pos + 7) / 8;
+            c.wchunks = std::max(c.wchunks, (n_pos + 7) / 8);
+            fma_chunks += (n_pos + 7) / 8;
+        }
         // lane runs in the output area: a multiple of 4 floats whose quarter is odd keeps the 16-byte accesses of 64 lanes on distinct banks
         // (runs that are not a multiple of 4 floats are stored float by float: any odd stride is conflict-free)
-        c.ls = L % 4 == 0 ? ((L / 4) % 2 == 1 ? (int)L : (int)L + 4) : (L % 2 == 1 ? (int)L : (int)L + 1);
+        auto lane_stride = [](int64_t n) { return n % 4 == 0 ? ((n / 4) % 2 == 1 ? (int)n : (int)n + 4) : (n % 2 == 1 ? (int)n : (int)n + 1); };
+        c.ls = lane_stride(L);
         // lane blocks per tile: as many as LDS and the prefetch registers hold
         for (int cand = 1; cand <= 64; ++cand) {
             const int64_t t_in = c.wlen + (int64_t)cand * 64 * c.D + c.i_max + 1;
-            const int64_t bytes = 4 * (((t_in + 3) & ~(int64_t)3) + (int64_t)cand * 64 * c.ls);
+            const int64_t l_in = lds_pos(((t_in + 3) & ~(int64_t)3) - 1) + 1;      // (samples move in pieces of 4)
+            const int64_t bytes = 4 * (((l_in + 3) & ~(int64_t)3) + (int64_t)cand * 64 * c.ls);
             const int tasks = cand * c.groups;
             const int rounds = (tasks + 15) / 16;
             const int nw = (tasks + rounds - 1) / rounds;
-            if (bytes > kPhaseLdsBytes || t_in > (int64_t)kPhasePF * 64 * nw) break;
-            c.nb = cand; c.threads = 64 * nw; c.tile_in = (int)t_in;
-            c.cost = (double)rounds * ((nw + 3) / 4) * c.wlen * Q / ((double)cand * 64 * L);
+            if (bytes > kPhaseLdsBytes || t_in > (int64_t)kPhasePF * 64 * nw || t_in * c.D >= (int64_t)1 << 31) break;
+            c.nb = cand; c.threads = 64 * nw; c.tile_in = (int)t_in; c.lds_in = (int)l_in;
+            c.cost = (double)rounds * ((nw + 3) / 4) * 8.0 * fma_chunks / c.groups * Q / ((double)cand * 64 * L);
+        }
+        if (c.nb == 0) {
+            // One lane block's outputs do not fit beside its staged input (22.05 -> 16 kHz: 112 + 80 KB): the outputs leave round by
+            // round of the block's waves instead, through an area of 64 lanes x (waves * Q) floats.
+            const int64_t t_in = c.wlen + (int64_t)64 * c.D + c.i_max + 1;
+            const int64_t l_in = lds_pos(((t_in + 3) & ~(int64_t)3) - 1) + 1;
+            for (int nw = 16; nw >= 4 && c.nb == 0; --nw) {
+                if (nw > c.groups) continue;
+                const int round_out = nw * Q;
+                const int ls_r = lane_stride(round_out);
+                const int64_t bytes = 4 * (((l_in + 3) & ~(int64_t)3) + (int64_t)64 * ls_r);
+                if (bytes > kPhaseLdsBytes || t_in > (int64_t)kPhasePF * 64 * nw || t_in * c.D >= (int64_t)1 << 31) continue;
+                const int rounds = (c.groups + nw - 1) / nw;
+                c.nb = 1; c.threads = 64 * nw; c.tile_in = (int)t_in; c.lds_in = (int)l_in; c.ls = ls_r; c.round_out = round_out;
+                c.cost = 1.05 * (double)rounds * ((nw + 3) / 4) * 8.0 * fma_chunks / c.groups * Q / ((double)64 * L);      // (the rounds' barriers)
+            }
         }
         if (c.nb > 0 && (best.Q == 0 || c.cost < best.cost)) best = c;
     }
     if (best.Q == 0) return MMFE_OK;
-    const int Q = best.Q, wlen = best.wlen;
-    std::vector<float> wt((size_t)best.groups * wlen * Q, 0.f);
-    for (int u = 0; u < best.groups; ++u)
-        for (int sidx = 0; sidx < wlen; ++sidx)
-            for (int q = 0; q < Q; ++q) {
-                const int t = sidx - (best.gi[u] - best.io[u * Q + q]);
-                if (t >= 0 && t < taps)
-                    wt[(((size_t)u * (wlen / 8) + sidx / 8) * Q + q) * 8 + sidx % 8] = bank[(size_t)best.ph[u * Q + q] * taps_padded + t];
+    const int Q = best.Q;
+    {
+        // weights by LDS position: position s of run u holds staged sample top - s', where s' counts only the samples (the unused
+        // floats of a padded layout keep weight zero)
+        const Layout& c = best;
+        auto lds_pos = [&](int64_t k) { return k + (c.pad ? k / c.D : 0); };
+        std::vector<float> wt((size_t)c.groups * c.wchunks * 8 * Q, 0.f);
+        for (int u = 0; u < c.groups; ++u) {
+            const int64_t top = c.wlen + c.last[u];
+            for (int back = 0; back <= taps - 1 + c.last[u] - c.io[u * Q]; ++back) {          // sample top - back
+                const int pos = (int)(lds_pos(top) - lds_pos(top - back));
+                for (int q = 0; q < Q; ++q) {
+                    const int t = back - (c.last[u] - c.io[u * Q + q]);
+                    if (t >= 0 && t < taps)
+                        wt[(((size_t)u * c.wchunks + pos / 8) * Q + q) * 8 + pos % 8] = bank[(size_t)c.ph[u * Q + q] * taps_padded + t];
+                }
             }
-    if ((rc = upload(&plan.d_tw_a, wt))) return rc;
-    if ((rc = upload(&plan.d_mel_start, best.gi))) return rc;
-    plan.rs_q = Q; plan.rs_L = best.L; plan.rs_D = best.D; plan.rs_nb = best.nb; plan.rs_groups = best.groups; plan.rs_wlen = wlen;
-    plan.rs_tile_in = best.tile_in; plan.rs_ls = best.ls; plan.rs_threads = best.threads;
+        }
+        if ((rc = upload(&plan.d_tw_a, wt))) return rc;
+        if ((rc = upload(&plan.d_mel_start, c.table))) return rc;
+    }
+    plan.rs_q = Q; plan.rs_L = best.L; plan.rs_D = best.D; plan.rs_nb = best.nb; plan.rs_groups = best.groups; plan.rs_wlen = best.wlen;
+    plan.rs_wchunks = best.wchunks; plan.rs_tile_in = best.tile_in; plan.rs_lds_in = best.lds_in; plan.rs_pad = best.pad;
+    plan.rs_round_out = best.round_out; plan.rs_ls = best.ls; plan.rs_threads = best.threads;
 
     // ---- 16-bit rows: the two-blocks-per-CU form (samples stay 16-bit in LDS, outputs leave round by round) ----
     plan.rs16_threads = 0;
@@ -697,14 +787,15 @@ int resample_launch(const Plan& plan, const RowSource& src, int64_t n_rows, int6
         a.n_out = n_out;
         a.out_stride = out_len;
         a.up = up; a.down = down;
-        a.L = plan.rs_L; a.D = plan.rs_D; a.nb = plan.rs_nb; a.groups = plan.rs_groups; a.wlen = plan.rs_wlen;
-        a.tile_in = plan.rs_tile_in; a.ls = plan.rs_ls;
+        a.L = plan.rs_L; a.D = plan.rs_D; a.nb = plan.rs_nb; a.groups = plan.rs_groups; a.wlen = plan.rs_wlen; a.wchunks = plan.rs_wchunks;
+        a.tile_in = plan.rs_tile_in; a.lds_in = plan.rs_lds_in; a.pad = plan.rs_pad; a.ls = plan.rs_ls; a.round_out = plan.rs_round_out;
+        a.inv_D = (unsigned)(((uint64_t)1 << 32) / (uint64_t)a.D + 1);
         a.tile_out = a.nb * 64 * a.L;
         a.tiles_per_row = (int)((n_out + a.tile_out - 1) / a.tile_out);
         a.wt = plan.d_tw_a;
         a.gi = plan.d_mel_start;
         a.vec_out = (reinterpret_cast<uintptr_t>(out) % 16 == 0 && out_len % 4 == 0 && a.L % 4 == 0) ? 1 : 0;
-        const size_t lds = 4 * ((size_t)((a.tile_in + 3) & ~3) + (size_t)a.nb * 64 * a.ls);
+        const size_t lds = 4 * ((size_t)((a.lds_in + 3) & ~3) + (size_t)a.nb * 64 * a.ls);
         // whole four-sample pieces: rows on 4-sample boundaries of aligned memory, a multiple of 4 samples each, no per-row lengths
         const bool vec = src.offsets == nullptr && src.row_len == nullptr && n_samples % 4 == 0 && n_samples >= 4 && src.stride % 4 == 0 &&
                          reinterpret_cast<uintptr_t>(src.base) % (pcm ? 8 : 16) == 0;

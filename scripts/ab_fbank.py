@@ -29,7 +29,7 @@ from multi_modal_amd import _native as N          # noqa: E402
 from multi_modal_amd import kaldi, plans, vggsound  # noqa: E402
 
 
-def build_plan(path, device, in_dtype=N.IN_F32, config="vgg"):
+def build_plan(path, device, in_dtype=N.IN_F32, config="vgg", ratio=(160, 441)):
     """The configuration's plan, created through the library at `path`."""
     N._lib = N.bind_library(path)
     plans._plans.clear()            # plans of the previous library stay alive in the caller's list
@@ -41,7 +41,7 @@ def build_plan(path, device, in_dtype=N.IN_F32, config="vgg"):
         return har._stft_plan(device, 32, 28)
     if config == "resample":
         from multi_modal_amd import resample
-        return resample._plan(device, 160, 441, 0, in_dtype)
+        return resample._plan(device, ratio[0], ratio[1], 0, in_dtype)
     kw = dict(vggsound._KW)
     plan = kaldi._fbank_plan(device, sample_frequency=kw["sample_frequency"], frame_length=25.0, frame_shift=kw["frame_shift"],
                              num_mel_bins=kw["num_mel_bins"], window_type=kw["window_type"], blackman_coeff=0.42,
@@ -58,7 +58,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--launches", type=int, default=20)
     ap.add_argument("--samples", type=int, default=160000)
-    ap.add_argument("--pcm", action="store_true", help="vgg / logmel: 16-bit PCM input")
+    ap.add_argument("--pcm", action="store_true", help="vgg / logmel / resample: 16-bit PCM input")
+    ap.add_argument("--ratio", default="160/441", help="resample: up/down (rows of --samples samples unless 160/441: ten seconds at 44.1 kHz)")
     ap.add_argument("builds", nargs="+", help="name=path pairs")
     args = ap.parse_args()
     torch.cuda.set_device(0)
@@ -69,7 +70,9 @@ def main():
     elif args.config == "logmel":
         rows, n, oshape = args.batch or 1024, 480000, (80, 3000)
     elif args.config == "resample":
-        rows, n, oshape = args.batch or 1024, 441000, (160000,)
+        ratio = tuple(int(v) for v in args.ratio.split("/"))
+        n = 441000 if ratio == (160, 441) else args.samples
+        rows, oshape = args.batch or 1024, (-(-n * ratio[0] // ratio[1]),)
     else:
         n = args.samples if args.samples != 160000 else 192          # --samples: window length (default 192)
         rows, oshape = 6 * (args.batch or 262144), (17, 1 + (n + 3) // 4)
@@ -89,7 +92,8 @@ def main():
             saved[k] = os.environ.get(k)
             os.environ[k] = v
         names.append(name)
-        plist.append(build_plan(os.path.abspath(path), 0, in_dtype=N.IN_S16 if args.pcm else N.IN_F32, config=args.config))
+        plist.append(build_plan(os.path.abspath(path), 0, in_dtype=N.IN_S16 if args.pcm else N.IN_F32, config=args.config,
+                                ratio=ratio if args.config == "resample" else None))
         for k, v in saved.items():
             if v is None:
                 del os.environ[k]

@@ -1287,6 +1287,47 @@ def test_resample_both_kernels_agree(mm, O, monkeypatch):
     assert np.abs(fast - slow).max() <= 1e-6
 
 
+@pytest.mark.parametrize("orig,target", [(16000, 44100), (16000, 22050), (48000, 44100), (44100, 48000), (22050, 16000), (32000, 44100)])
+@pytest.mark.parametrize("dtype", ["f32", "s16"])
+def test_resample_even_lane_strides_and_round_by_round_tiles(mm, O, orig, target, dtype):
+    """Ratios whose lanes sit an even number of samples apart (x/160, x/320: staged with one unused float per lane stride) and
+    22.05 -> 16 kHz, whose tile outputs leave round by round because they do not fit LDS beside the staged input: whole tiles,
+    a partial last tile, rows shorter than a tile, lengths that are not a multiple of 4, many rows, and data behind the batch."""
+    for rows, n in ((3, 120000), (2, 100003), (37, 9001), (1, 5)):
+        rng = np.random.default_rng(rows * 7 + n + orig)
+        guard = torch.full((rows * n + 64,), 9999, dtype=torch.int16 if dtype == "s16" else torch.float32, device="cuda")
+        x = guard[: rows * n].view(rows, n)
+        if dtype == "s16":
+            pcm = rng.integers(-32768, 32768, size=(rows, n), dtype=np.int16)
+            x.copy_(torch.from_numpy(pcm))
+            xf = pcm.astype(np.float32) / 32768.0
+        else:
+            xf = rng.uniform(-1, 1, size=(rows, n)).astype(np.float32)
+            x.copy_(torch.from_numpy(xf))
+        ref = O.resample_poly(xf, orig, target)
+        got = mm.resample_batch(x, orig, target).cpu().numpy()
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 4e-6, (rows, n, mm.plans.last_kernel())
+
+
+@pytest.mark.parametrize("orig,target", [(16000, 44100), (44100, 16000), (8000, 16000), (48000, 16000), (16000, 48000)])
+def test_resample_padded_staging_is_bit_identical(mm, monkeypatch, orig, target):
+    """MMFE_RESAMPLE_PAD (read at plan creation) forces the padded LDS layout on or off.  The unused floats carry weight zero, so
+    both layouts add the same products in the same order: the outputs must be the same bits - for lane strides of 1 and 2 samples
+    too, where a run's window crosses an unused float every one or two samples."""
+    g = torch.Generator(device="cuda").manual_seed(orig + target)
+    x = torch.rand(5, 70001, device="cuda", generator=g) * 2 - 1
+    outs = []
+    for pad in ("0", "1"):
+        mm.plans.clear_plans()
+        monkeypatch.setenv("MMFE_RESAMPLE_PAD", pad)
+        outs.append(mm.resample_batch(x, orig, target))
+        outs.append(mm.resample_batch(x[:, :70000].contiguous(), orig, target))
+    monkeypatch.delenv("MMFE_RESAMPLE_PAD")
+    mm.plans.clear_plans()
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
+
+
 @pytest.mark.parametrize("rows,n", [(3, 441000), (5, 100004), (2, 30000), (70, 61740), (1, 8), (2, 50002), (3, 50001)])
 def test_resample_pcm_two_block_form_is_bit_identical(mm, O, monkeypatch, rows, n):
     """16-bit rows of aligned batches take the form that keeps the samples 16-bit in LDS and runs two blocks per CU;
