@@ -108,6 +108,9 @@ __global__ void __launch_bounds__(kThreads) resample_kernel(const ResampleArgs p
 
 
 // ---- wave-uniform-phase kernel --------------------------------------------------------------------------------------
+#ifndef MMFE_RS_STAGE_FIRST
+#define MMFE_RS_STAGE_FIRST 0     // 1: the next tile is staged before this tile's outputs are stored (A/B builds)
+#endif
 #ifndef MMFE_RS_LOAD_ALL
 #define MMFE_RS_LOAD_ALL 0      // 1: every thread requests all its pieces of the next tile, staged or not (A/B builds)
 #endif
@@ -275,57 +278,62 @@ __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const 
     if (p.pad) {                                                        // the unused floats, once: staging never writes them
         for (int j = threadIdx.x; j * (p.D + 1) + p.D < p.lds_in; j += blockDim.x) s_x[j * (p.D + 1) + p.D] = 0.f;
     }
+    // ---- stage: the registers `fetch` filled -> LDS ----
+    auto stage = [&](unsigned tile) {
+        const unsigned row = tile / (unsigned)p.tiles_per_row;
+        const int m0 = (int)(tile - row * (unsigned)p.tiles_per_row) * p.tile_out;
+        const int lo = (m0 / p.up) * p.down - p.wlen;
+        const int n_row = row_samples(p.src, row, p.n_in);
+        // (a thread's LDS positions are the same in every tile; left visible, the optimiser keeps all of them in registers across
+        // the loop - 36 per thread in the padded layout - and spills)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        if (VEC) {
+#pragma unroll
+            for (int q = 0; q < kPieces; ++q) {
+                const int k = 4 * (tid + q * (int)blockDim.x);
+                const int g = lo + k;
+                const f32x4 v = (g >= 0 && g + 4 <= n_row) ? Piece<SMP>::decode(pv[q]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (k < p.tile_in) {
+                    if (!p.pad) {
+                        *reinterpret_cast<f32x4*>(s_x + k) = v;
+                    } else {                                      // (lds_in has room for the whole last piece)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) s_x[k + i + (int)__umulhi((unsigned)(k + i), p.inv_D)] = v[i];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < kPhasePF; ++q) {
+                const int k = tid + q * (int)blockDim.x;
+                const int g = lo + k;
+                if (k < p.tile_in) s_x[p.pad ? k + (int)__umulhi((unsigned)k, p.inv_D) : k] = (g >= 0 && g < n_row) ? sample_value(pf[q]) : 0.f;
+            }
+        }
+    };
+    // A step: request the next tile's samples, run this tile's multiply-adds, barrier, store this tile's outputs, stage the next
+    // tile, barrier.  Loads and stores return in order, so the stage's wait for its samples also covers the stores issued a moment
+    // before it.  Staging first (-DMMFE_RS_STAGE_FIRST=1: everything the wait covers is then a whole multiply-add phase old) measured
+    // the same to 4 % slower over eight ratios: the block's 16 waves meet at the barrier behind both anyway.
     fetch(blockIdx.x);
+    if (blockIdx.x < n_tiles) stage(blockIdx.x);
+    lds_barrier();
     for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         RS_STAMP(-1);
         const unsigned row = tile / (unsigned)p.tiles_per_row;
         const int m0 = (int)(tile - row * (unsigned)p.tiles_per_row) * p.tile_out;
-        // ---- stage: registers -> LDS (the previous tile's readers passed the barrier that ended its multiply-adds; its drain
-        //      reads the other LDS area) ----
-        {
-            const int lo = (m0 / p.up) * p.down - p.wlen;
-            const int n_row = row_samples(p.src, row, p.n_in);
-            // (a thread's LDS positions are the same in every tile; left visible, the optimiser keeps all of them in registers across
-            // the loop - 36 per thread in the padded layout - and spills)
-            int tid = threadIdx.x;
-            asm volatile("" : "+v"(tid));
-            if (VEC) {
-#pragma unroll
-                for (int q = 0; q < kPieces; ++q) {
-                    const int k = 4 * (tid + q * (int)blockDim.x);
-                    const int g = lo + k;
-                    const f32x4 v = (g >= 0 && g + 4 <= n_row) ? Piece<SMP>::decode(pv[q]) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (k < p.tile_in) {
-                        if (!p.pad) {
-                            *reinterpret_cast<f32x4*>(s_x + k) = v;
-                        } else {                                      // (lds_in has room for the whole last piece)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) s_x[k + i + (int)__umulhi((unsigned)(k + i), p.inv_D)] = v[i];
-                        }
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < kPhasePF; ++q) {
-                    const int k = tid + q * (int)blockDim.x;
-                    const int g = lo + k;
-                    if (k < p.tile_in) s_x[p.pad ? k + (int)__umulhi((unsigned)k, p.inv_D) : k] = (g >= 0 && g < n_row) ? sample_value(pf[q]) : 0.f;
-                }
-            }
-        }
-        RS_STAMP(0);      // stage
-        lds_barrier();
-        RS_STAMP(1);      // barrier after stage
         // The next tile's samples, requested here all at once.  s_memtime stamps (-DMMFE_RS_STAMPS) show the later waves of a block
         // sitting in the issue of these loads for up to 4 000 of a step's 24 000 cycles (16 waves x 9 loads pass the CU's 64 B/clk
         // path to L1 one after the other).  Having each wave request one piece per chunk of its first run instead moves the waiting
         // into the runs and the step takes as long (measured: 16-bit rows +0.6 %, float32 rows +5 %).
         fetch(tile + gridDim.x);
-        RS_STAMP(2);      // fetch issue
+        RS_STAMP(0);      // fetch issue
         // ---- runs: (lane block, group) pairs spread over the waves.  Every wave takes the same number of turns (rounds end in
         //      barriers when the outputs leave round by round); a turn beyond the last run is empty. ----
         const int n_tasks = p.nb * p.groups;
-        for (int t0 = 0, r = 0; t0 < n_tasks; t0 += n_waves, ++r) {
+        int r = 0;
+        for (int t0 = 0; t0 < n_tasks; t0 += n_waves, ++r) {
             const int task = t0 + wave;
             if (task < n_tasks) {
                 const int blk = task / p.groups;
@@ -364,29 +372,31 @@ __global__ void __launch_bounds__(kMaxPhaseThreads) resample_phase_kernel(const 
                     for (int q = 0; q < Q; ++q) so[q] = acc[q];
                 }
             }
-            if (p.round_out > 0) {
+            if (p.round_out > 0 && t0 + n_waves < n_tasks) {          // every round but the last: its outputs leave here
                 lds_barrier();
                 drain_round(row, m0, r);
-                // the output area is written again at the end of the next round's runs; the last round needs no barrier here: the
-                // barrier behind the next tile's stage stands between these reads and those writes
-                if (t0 + n_waves < n_tasks) lds_barrier();
+                lds_barrier();                                        // (the output area is written again at the end of the next round's runs)
             }
         }
-        RS_STAMP(3);      // runs
-        if (p.round_out == 0) {
-            lds_barrier();
-            RS_STAMP(4);      // barrier after runs
-            // (storing a tile's outputs one step later instead - after the next tile is staged and before its samples' successors are
-            // requested, so that no stage ever waits behind stores - measured 6 % (16-bit input) to 16 % (float32) slower)
-            drain(row, m0);
-            RS_STAMP(5);      // drain
-            // (no barrier here: the next step's stage only writes s_x, whose readers passed the barrier above, and s_o is not written
-            // again before the barrier that follows the stage)
-        }
+        RS_STAMP(1);      // runs
+        lds_barrier();    // the tile's readers are done with the staged samples; its (last round of) outputs are complete
+        RS_STAMP(2);      // barrier after runs
+#if MMFE_RS_STAGE_FIRST
+        if (tile + gridDim.x < n_tiles) stage(tile + gridDim.x);
+        RS_STAMP(3);      // stage
+#endif
+        if (p.round_out > 0) drain_round(row, m0, r - 1);
+        else drain(row, m0);
+        RS_STAMP(4);      // drain
+#if !MMFE_RS_STAGE_FIRST
+        if (tile + gridDim.x < n_tiles) stage(tile + gridDim.x);
+#endif
+        lds_barrier();    // the next tile's samples are in place; the output area is free
+        RS_STAMP(5);      // barrier after stage and drain
     }
 #ifdef MMFE_RS_STAMPS
     if (blockIdx.x == 3 && lane == 0 && (wave == 0 || wave == 9))
-        printf("wave %d, shader-clock cycles: stage %llu  barrier %llu  load issue %llu  runs %llu  barrier %llu  drain %llu\n", wave, st_acc[0], st_acc[1], st_acc[2], st_acc[3], st_acc[4], st_acc[5]);
+        printf("wave %d, shader-clock cycles: load issue %llu  runs %llu  barrier %llu  stage %llu  drain %llu  barrier %llu\n", wave, st_acc[0], st_acc[1], st_acc[2], st_acc[3], st_acc[4], st_acc[5]);
 #endif
 }
 
@@ -447,27 +457,52 @@ __global__ void __launch_bounds__(kMaxPhaseThreads, 8) resample_phase16_kernel(c
             pv[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(x + (g < 0 ? 0 : (g + 4 <= p.n_in ? g : p.n_in - 4))));
         }
     };
-    fetch(blockIdx.x);
-    for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // ---- stage: the pieces as they are, zeros outside the row ----
+    auto stage = [&](unsigned tile) {
         const unsigned row = tile / (unsigned)p.tiles_per_row;
         const int m0 = (int)(tile - row * (unsigned)p.tiles_per_row) * p.tile_out;
         const int lo = (m0 / p.up) * p.down - p.wlen;
-        // ---- stage: the pieces as they are, zeros outside the row (the previous tile's readers passed the barrier behind its last round) ----
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));       // (keeps the nine LDS positions from being held in registers across the loop)
         if (MMFE_RS16_INTERIOR && lo >= 0 && lo + span <= p.n_in) {
 #pragma unroll
             for (int q = 0; q < kPieces; ++q) {
-                const int k = 4 * ((int)threadIdx.x + q * (int)blockDim.x);
+                const int k = 4 * (tid + q * (int)blockDim.x);
                 if (k < p.tile_in) *reinterpret_cast<u32x2*>(s_x + k) = pv[q];
             }
         } else {
 #pragma unroll
             for (int q = 0; q < kPieces; ++q) {
-                const int k = 4 * ((int)threadIdx.x + q * (int)blockDim.x);
+                const int k = 4 * (tid + q * (int)blockDim.x);
                 const int g = lo + k;
                 if (k < p.tile_in) *reinterpret_cast<u32x2*>(s_x + k) = (g >= 0 && g + 4 <= p.n_in) ? pv[q] : u32x2{0u, 0u};
             }
         }
-        lds_barrier();
+    };
+    // ---- a round's outputs: lane run j holds outputs m0 + j * L + r * round_out .. + round_out - 1 ----
+    auto drain_round = [&](float* orow, int m0, int r, bool whole) {
+        if (whole) {
+            const int r4 = pp.round_out >> 2;                   // 16-byte pieces per lane run
+            for (int i = threadIdx.x; i < 64 * r4; i += blockDim.x) {
+                const int j = i / r4, k = i - j * r4;
+                __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(s_o + j * p.ls + 4 * k),
+                                            reinterpret_cast<f32x4*>(orow + (int64_t)j * p.L + r * pp.round_out) + k);
+            }
+        } else {
+            for (int i = threadIdx.x; i < 64 * pp.round_out; i += blockDim.x) {
+                const int j = i / pp.round_out, k = i - j * pp.round_out;
+                const int64_t m = (int64_t)j * p.L + r * pp.round_out + k;
+                if (m0 + m < p.n_out) __builtin_nontemporal_store(s_o[j * p.ls + k], orow + m);
+            }
+        }
+    };
+    // step order as in resample_phase_kernel
+    fetch(blockIdx.x);
+    if (blockIdx.x < n_tiles) stage(blockIdx.x);
+    lds_barrier();
+    for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const unsigned row = tile / (unsigned)p.tiles_per_row;
+        const int m0 = (int)(tile - row * (unsigned)p.tiles_per_row) * p.tile_out;
         fetch(tile + gridDim.x);
         float* orow = p.out + (int64_t)row * p.out_stride + m0;
         const bool whole = p.vec_out && m0 + p.tile_out <= p.n_out;
@@ -502,25 +537,20 @@ __global__ void __launch_bounds__(kMaxPhaseThreads, 8) resample_phase16_kernel(c
                 for (int q = 0; q < Q; ++q) so[q] = acc[q];
             }
             lds_barrier();
-            // ---- the round's outputs: lane run j holds outputs m0 + j * L + r * round_out .. + round_out - 1 ----
-            if (whole) {
-                const int r4 = pp.round_out >> 2;                   // 16-byte pieces per lane run
-                for (int i = threadIdx.x; i < 64 * r4; i += blockDim.x) {
-                    const int j = i / r4, k = i - j * r4;
-                    __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(s_o + j * p.ls + 4 * k),
-                                                reinterpret_cast<f32x4*>(orow + (int64_t)j * p.L + r * pp.round_out) + k);
-                }
-            } else {
-                for (int i = threadIdx.x; i < 64 * pp.round_out; i += blockDim.x) {
-                    const int j = i / pp.round_out, k = i - j * pp.round_out;
-                    const int64_t m = (int64_t)j * p.L + r * pp.round_out + k;
-                    if (m0 + m < p.n_out) __builtin_nontemporal_store(s_o[j * p.ls + k], orow + m);
-                }
+            if (r + 1 < pp.rounds) {
+                drain_round(orow, m0, r, whole);
+                lds_barrier();                      // (the output area is written again at the end of the next round's runs)
             }
-            // the output area is written again at the end of the next round's runs; a round that is followed by the stage of the
-            // next tile needs no barrier here: the barrier behind that stage stands between these reads and those writes
-            if (r + 1 < pp.rounds) lds_barrier();
         }
+        // (the barrier behind the last round: the tile's readers are done with the staged samples)
+#if MMFE_RS_STAGE_FIRST
+        if (tile + gridDim.x < n_tiles) stage(tile + gridDim.x);
+#endif
+        drain_round(orow, m0, pp.rounds - 1, whole);
+#if !MMFE_RS_STAGE_FIRST
+        if (tile + gridDim.x < n_tiles) stage(tile + gridDim.x);
+#endif
+        lds_barrier();
     }
 }
 
