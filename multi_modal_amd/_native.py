@@ -17,7 +17,7 @@ _lib = None
 _lib_lock = threading.Lock()
 
 # --- constants mirrored from include/mmfe.h -------------------------------------------------------
-ABI_VERSION = 6
+ABI_VERSION = 7
 KIND_FBANK, KIND_LOGSPEC, KIND_STFT_MAG, KIND_FRAME, KIND_RESAMPLE = 1, 2, 3, 4, 5
 PAD_NONE, PAD_ZERO, PAD_REFLECT = 0, 1, 2
 FRAMES_SNIP, FRAMES_CENTER, FRAMES_SCIPY, FRAMES_CEIL = 0, 1, 2, 3
@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = (
     "mmfe_abi_version", "mmfe_last_error", "mmfe_device_count", "mmfe_spec_out_shape",
     "mmfe_plan_create", "mmfe_plan_destroy", "mmfe_run", "mmfe_run_noalloc", "mmfe_run_slices", "mmfe_run_ragged", "mmfe_run_slices_ragged", "mmfe_feature_sums",
     "mmfe_plan_kernel",
+    "mmfe_patch_embed_create", "mmfe_patch_embed_destroy", "mmfe_patch_embed_shape", "mmfe_patch_embed_run",
 )
 
 
@@ -116,6 +117,15 @@ def bind_library(path: str):
     lib.mmfe_feature_sums.argtypes = [c_f_p, c_i64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     lib.mmfe_plan_kernel.restype = ctypes.c_char_p
     lib.mmfe_plan_kernel.argtypes = [ctypes.c_void_p]
+    lib.mmfe_patch_embed_create.restype = ctypes.c_int
+    lib.mmfe_patch_embed_create.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_int32, ctypes.c_int32, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    lib.mmfe_patch_embed_destroy.restype = ctypes.c_int
+    lib.mmfe_patch_embed_destroy.argtypes = [ctypes.c_void_p]
+    lib.mmfe_patch_embed_shape.restype = ctypes.c_int
+    lib.mmfe_patch_embed_shape.argtypes = [ctypes.c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]
+    lib.mmfe_patch_embed_run.restype = ctypes.c_int
+    lib.mmfe_patch_embed_run.argtypes = [ctypes.c_void_p, c_f_p, c_i64, c_i64, c_f_p, c_i64, ctypes.c_void_p]
     if lib.mmfe_abi_version() != ABI_VERSION:
         raise MmfeError(f"{path} has ABI version {lib.mmfe_abi_version()}, the Python side expects {ABI_VERSION}")
     return lib
@@ -238,3 +248,42 @@ def feature_sums_ptr(x_ptr: int, n: int, sums_ptr: int, device: int, stream: int
     lib = load_library()
     check(lib.mmfe_feature_sums(x_ptr, int(n), sums_ptr, int(device), ctypes.c_void_p(stream) if stream else None),
           "mmfe_feature_sums")
+
+
+class PatchEmbedHandle:
+    """Owns one mmfe_patch_embed (the 16 x 16 / stride-16 patch convolution's weights in matrix-pipe operand order on one device)."""
+
+    def __init__(self, height: int, width: int, weight: np.ndarray, bias: Optional[np.ndarray], compute_dtype: int, out_dtype: int,
+                 device: int = 0, patch: int = 16):
+        self._lib = load_library()
+        w = np.ascontiguousarray(weight, dtype=np.float32)
+        if w.ndim != 2 or w.shape[1] != patch * patch:
+            raise ValueError(f"weight must be (embed_dim, {patch * patch}), got {w.shape}")
+        b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+        if b is not None and b.shape != (w.shape[0],):
+            raise ValueError(f"bias must have {w.shape[0]} entries, got {b.shape}")
+        handle = ctypes.c_void_p()
+        check(self._lib.mmfe_patch_embed_create(int(height), int(width), int(patch), int(w.shape[0]), w.ctypes.data_as(ctypes.c_void_p),
+                                                None if b is None else b.ctypes.data_as(ctypes.c_void_p), int(compute_dtype),
+                                                int(out_dtype), int(device), ctypes.byref(handle)), "mmfe_patch_embed_create")
+        self._handle = handle
+        self.device = int(device)
+        self.out_dtype = int(out_dtype)
+        n, e = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(self._lib.mmfe_patch_embed_shape(self._handle, ctypes.byref(n), ctypes.byref(e)), "mmfe_patch_embed_shape")
+        self.n_patches, self.embed_dim = int(n.value), int(e.value)
+
+    def run_ptr(self, x_ptr: int, x_batch_stride: int, n_batch: int, out_ptr: int, out_batch_stride: int, stream: int = 0) -> None:
+        check(self._lib.mmfe_patch_embed_run(self._handle, x_ptr, int(x_batch_stride), int(n_batch), out_ptr, int(out_batch_stride),
+                                             ctypes.c_void_p(stream) if stream else None), "mmfe_patch_embed_run")
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            self._lib.mmfe_patch_embed_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

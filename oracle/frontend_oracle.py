@@ -27,6 +27,9 @@ order those libraries use:
 * frame_signal -> classification/vggsound/utils/transforms.py:19-61 (identical
   copies under recognition/ and retrieval/).  Pinned by outputs of the
   reference function itself (tests/golden/frame_signal.npz).
+* patch_embed -> PatchEmbed.forward (classification/vggsound/models/vit_model.py:193-199) with the projection
+  AudioTransformer installs (vit_model.py:435), as @autocast() (vit_model.py:388) evaluates it: operands rounded
+  to the 16-bit type, float32 sums.  Pinned by outputs of the reference's own class (tests/golden/patch_embed.npz).
 * whisper_logmel -> not in the reference at all; the "n_fft=400 hop=160 80-mel
   30 s" configuration is defined by transformers' WhisperFeatureExtractor and
   is restated here only so the throughput configuration has a checker.
@@ -304,3 +307,24 @@ def resample_poly(x, orig_sr: int, target_sr: int):
     import scipy.signal
     g = math.gcd(int(orig_sr), int(target_sr))
     return scipy.signal.resample_poly(np.asarray(x, dtype=np.float32), int(target_sr) // g, int(orig_sr) // g, axis=-1)
+
+
+# ---------------------------------------------------------------------------------------------
+# patch embedding (classification/vggsound/models/vit_model.py:179-199, 435)
+def patch_embed(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None, compute_dtype=torch.float16,
+                out_dtype=torch.float32, patch: int = 16) -> torch.Tensor:
+    """`self.proj(x).flatten(2).transpose(1, 2)` (vit_model.py:198) for proj = Conv2d(1, E, 16, stride 16) (vit_model.py:435),
+    x (B, 1, H, W) or (B, H, W) -> (B, P, E).  compute_dtype None: the plain float32 convolution, as the module computes outside
+    autocast.  Otherwise the autocast evaluation (vit_model.py:388): image, weight and bias rounded to compute_dtype, products
+    of those values summed in higher precision (float64 here, so that the checker's own summation error stays out of the
+    comparison), result rounded to out_dtype."""
+    if x.dim() == 3:
+        x = x[:, None]
+    if weight.dim() == 2:
+        weight = weight.reshape(weight.shape[0], 1, patch, patch)
+    if compute_dtype is None:
+        y = torch.nn.functional.conv2d(x.float(), weight.float(), None if bias is None else bias.float(), stride=patch)
+    else:
+        r = lambda t: t.to(compute_dtype).to(torch.float64)
+        y = torch.nn.functional.conv2d(r(x.float()), r(weight.float()), None if bias is None else r(bias.float()), stride=patch)
+    return y.flatten(2).transpose(1, 2).to(out_dtype)

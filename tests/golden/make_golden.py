@@ -27,6 +27,11 @@ What pins what
                       (classification/recognition/dataset/transform.py:253-285, 63-76; wired at epic_kitchen.py:62-66),
                       class definitions compiled from the file's AST, fed the mode-'F' PIL image epic_kitchen.py:176
                       builds  -> PINNED
+  patch_embed.npz     tokens computed by the reference's own PatchEmbed class (classification/vggsound/models/vit_model.py:179-199),
+                      class definition compiled from the file's AST (the module import needs timm), built the way
+                      AudioTransformer builds its audio projection (vit_model.py:435: Conv2d(1, E, (16, 16), stride 16)) with
+                      seeded weights, run in float32 on seeded (B, 1, H, W) images  -> PINNED (patch order, weight layout,
+                      flatten / transpose; the 16-bit rounding of autocast is restated by the oracle on top of it)
 Inputs are regenerated from tests/conftest.synth (integer PRNG), so no waveform is stored.
 """
 import ast
@@ -267,6 +272,49 @@ def resample():
     print("resample.npz", len(out), "arrays")
 
 
+PATCH_CASES = [  # name, B, H, W, E, seed, token stride of the stored subset
+    ("vgg", 2, 384, 128, 768, 501, 13),        # (B, 1, 384, 128): audio.unsqueeze(1) of the VGGSound tensor, 192 tokens
+    ("epic", 1, 256, 256, 768, 502, 17),       # audio.view(-1, 1, 256, 256), 256 tokens
+    ("small", 3, 32, 48, 384, 503, 1),
+    ("ragged", 2, 40, 52, 384, 504, 1),        # rows / columns beyond the last whole patch are ignored by the convolution
+]
+
+
+def patch_embed_inputs(B, H, W, E, seed):
+    """Dyadic values with few significant bits: exact in float16 and bfloat16, and every partial sum of the 256 products is exact
+    in float32, so the float32 convolution has ONE right answer whatever the summation order or operand rounding."""
+    rng = np.random.default_rng(seed)
+    x = rng.integers(-12, 13, size=(B, 1, H, W)).astype(np.float32) / 4.0
+    w = rng.integers(-8, 9, size=(E, 1, 16, 16)).astype(np.float32) / 16.0
+    b = rng.integers(-64, 65, size=(E,)).astype(np.float32) / 8.0
+    return x, w, b
+
+
+def patch_embed():
+    from collections import abc
+    from itertools import repeat
+    ns = {"torch": torch, "nn": torch.nn, "abc": abc, "repeat": repeat}
+    # Read before it was run here: to_2tuple is a two-line tuple helper, PatchEmbed an nn.Module holding one Conv2d whose forward is
+    # `self.proj(x).flatten(2).transpose(1, 2)`; no imports, I/O or calls beyond torch.nn.
+    _, PatchEmbed = _reference_defs("classification/vggsound/models/vit_model.py", ["to_2tuple", "PatchEmbed"], ns)
+    out = {}
+    for name, B, H, W, E, seed, step in PATCH_CASES:
+        x, w, b = patch_embed_inputs(B, H, W, E, seed)
+        pe = PatchEmbed(img_size=224, patch_size=16, in_chans=3, embed_dim=E)          # as VisionTransformer.__init__ builds it
+        proj = torch.nn.Conv2d(1, E, kernel_size=(16, 16), stride=(16, 16))            # vit_model.py:435, fstride = tstride = 16
+        with torch.no_grad():
+            proj.weight.copy_(torch.from_numpy(w))
+            proj.bias.copy_(torch.from_numpy(b))
+            pe.proj = proj                                                             # vit_model.py:439
+            y = pe(torch.from_numpy(x)).numpy()
+        assert y.shape == (B, (H // 16) * (W // 16), E)
+        out[name + "_shape"] = np.array([B, H, W, E, seed, step])
+        out[name + "_tokens"] = y[:, ::step].copy()
+        out[name + "_sums"] = np.array([y.astype(np.float64).sum(), (y.astype(np.float64) ** 2).sum()])
+    np.savez_compressed(os.path.join(HERE, "patch_embed.npz"), **out)
+    print("patch_embed.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:
         for name in sys.argv[1:]:
@@ -280,3 +328,4 @@ if __name__ == "__main__":
     resample()
     epic_slices()
     spec_transform()
+    patch_embed()

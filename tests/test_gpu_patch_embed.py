@@ -1,0 +1,153 @@
+"""Patch embedding (csrc/patch_embed.hip through the C ABI, mmfe_patch_embed_*) against
+  * tokens the reference's own PatchEmbed class computed (tests/golden/patch_embed.npz, made by make_golden.py from
+    classification/vggsound/models/vit_model.py:179-199 with the projection of vit_model.py:435) on dyadic data whose float32
+    convolution has one right answer: bit exact;
+  * the oracle's restatement of the autocast evaluation (operands rounded to the 16-bit type, exact sums) on random data:
+    float32 tokens within 2e-5 * sum |x w| (float32 accumulation of 256 products), 16-bit tokens within one unit in the last
+    place of the 16-bit type.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["vgg", "epic", "small", "ragged"]
+
+
+@pytest.fixture(scope="module")
+def mm():
+    import multi_modal_amd as m
+    m.load_library()
+    assert torch.cuda.is_available()
+    return m
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import frontend_oracle
+    return frontend_oracle
+
+
+def dyadic(B, H, W, E, seed):
+    """The generator of tests/golden/make_golden.py: values exact in float16 and bfloat16, every partial sum exact in float32."""
+    rng = np.random.default_rng(seed)
+    x = rng.integers(-12, 13, size=(B, 1, H, W)).astype(np.float32) / 4.0
+    w = rng.integers(-8, 9, size=(E, 1, 16, 16)).astype(np.float32) / 16.0
+    b = rng.integers(-64, 65, size=(E,)).astype(np.float32) / 8.0
+    return torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b)
+
+
+@pytest.mark.parametrize("compute", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", CASES)
+def test_patch_embed_golden_reference_class(mm, golden_dir, case, compute):
+    from multi_modal_amd.patch_embed import PatchEmbed
+    z = np.load(os.path.join(golden_dir, "patch_embed.npz"))
+    B, H, W, E, seed, step = (int(v) for v in z[case + "_shape"])
+    x, w, b = dyadic(B, H, W, E, seed)
+    pe = PatchEmbed((H, W), w, b, compute_dtype=compute)
+    y = pe(x.cuda()).cpu().numpy()
+    assert y.shape == (B, (H // 16) * (W // 16), E)
+    assert np.array_equal(y[:, ::step], z[case + "_tokens"])
+    sums = np.array([y.astype(np.float64).sum(), (y.astype(np.float64) ** 2).sum()])
+    assert np.array_equal(sums, z[case + "_sums"])
+    y16 = PatchEmbed((H, W), w, b, compute_dtype=compute, out_dtype=compute)(x.cuda())
+    assert y16.dtype == compute and torch.equal(y16.cpu(), torch.from_numpy(y).to(compute))      # exact sums, rounded once
+
+
+def test_patch_embed_many_steps_per_block_bit_exact(mm, O):
+    """300 VGGSound-shaped images = 900 steps of 64 patches over 256 persistent blocks: every block runs its double-buffered
+    loop three or four times.  Dyadic data, so a tile read before its DMA has landed (or after the next one has) shows as a wrong
+    bit somewhere; the float32 convolution is the checker."""
+    from multi_modal_amd.patch_embed import PatchEmbed
+    B, H, W, E = 300, 384, 128, 768
+    rng = np.random.default_rng(77)
+    x = torch.from_numpy(rng.integers(-12, 13, size=(B, H, W)).astype(np.float32) / 4.0)
+    _, w, b = dyadic(1, 16, 16, E, 78)
+    ref = O.patch_embed(x, w, b, compute_dtype=None)
+    pe = PatchEmbed((H, W), w, b, compute_dtype=torch.bfloat16)
+    xd = x.cuda()
+    for _ in range(3):
+        y = pe(xd)
+        assert torch.equal(y.cpu(), ref)
+    y16 = PatchEmbed((H, W), w, b, compute_dtype=torch.float16, out_dtype=torch.float16)(xd)
+    assert torch.equal(y16.cpu(), ref.to(torch.float16))
+
+
+@pytest.mark.parametrize("E", [384, 768])
+@pytest.mark.parametrize("compute", [torch.float16, torch.bfloat16])
+def test_patch_embed_random_against_oracle(mm, O, compute, E):
+    from multi_modal_amd.patch_embed import PatchEmbed
+    g = torch.Generator().manual_seed(5 + E)
+    B, H, W = 5, 128, 384                                           # the (B, 1, 128, 384) image layout: 24 patches per row
+    x = torch.randn(B, 1, H, W, generator=g) * 1.5 - 0.3
+    w = torch.randn(E, 1, 16, 16, generator=g) * 0.05
+    b = torch.randn(E, generator=g) * 0.1
+    ref = O.patch_embed(x, w, b, compute_dtype=compute, out_dtype=torch.float64)
+    scale = O.patch_embed(x.abs(), w.abs(), None, compute_dtype=compute, out_dtype=torch.float64)      # sum |x w| per token
+    y = PatchEmbed((H, W), w, b, compute_dtype=compute)(x.cuda()).cpu().double()
+    assert ((y - ref).abs() <= 2e-5 * scale + 1e-6).all()
+    for out_dtype in (torch.float16, torch.bfloat16):
+        y16 = PatchEmbed((H, W), w, b, compute_dtype=compute, out_dtype=out_dtype)(x.cuda()).cpu()
+        ulp = torch.finfo(out_dtype).eps * ref.abs().clamp_min(2.0 ** -14)
+        assert ((y16.double() - ref).abs() <= ulp + 2e-5 * scale).all()
+    # and against the plain float32 module (no autocast): the 16-bit rounding of the operands is all that separates them
+    plain = O.patch_embed(x, w, b, compute_dtype=None).double()
+    assert ((y - plain).abs() <= 2.5 * torch.finfo(compute).eps * scale + 1e-4).all()
+
+
+def test_patch_embed_out_with_class_token_row_and_strided_batch(mm, O):
+    """`out` one row longer than the patches: row 0 is left for the class token (vit_model.py:382-383); images taken from a
+    larger buffer (batch stride > H * W); a CPU tensor goes over and comes back."""
+    from multi_modal_amd.patch_embed import PatchEmbed
+    B, H, W, E = 7, 64, 48, 384                    # 12 patches per image, 84 in all: one full step and a partial one
+    x, w, b = dyadic(B, H, W, E, 91)
+    ref = O.patch_embed(x, w, b, compute_dtype=None)
+    pe = PatchEmbed((H, W), w, b)
+    big = torch.zeros(B, H + 5, W, device="cuda")
+    big[:, :H] = x[:, 0].cuda()
+    tokens = torch.full((B, 13, E), -7.0, device="cuda")
+    r = pe(big[:, :H], out=tokens)
+    assert r.data_ptr() == tokens.data_ptr()
+    assert torch.equal(tokens[:, 1:].cpu(), ref) and bool((tokens[:, 0] == -7.0).all())
+    y_cpu = pe(x)
+    assert not y_cpu.is_cuda and torch.equal(y_cpu, ref)
+    assert pe(x[:0].cuda()).shape == (0, 12, E)
+    with pytest.raises(ValueError):
+        pe(torch.zeros(2, H, W + 16, device="cuda"))
+
+
+def test_patch_embed_refusals(mm):
+    from multi_modal_amd import MmfeError
+    from multi_modal_amd.patch_embed import PatchEmbed
+    w = torch.zeros(768, 1, 16, 16)
+    with pytest.raises(MmfeError):
+        PatchEmbed((64, 64), torch.zeros(192, 1, 16, 16))             # embedding size without a kernel instance
+    with pytest.raises(MmfeError):
+        PatchEmbed((8, 64), w)                                        # smaller than one patch
+    with pytest.raises(ValueError):
+        PatchEmbed((64, 64), torch.zeros(768, 3, 16, 16))             # the audio projection has one input channel
+    with pytest.raises(ValueError):
+        PatchEmbed((64, 64), w, compute_dtype=torch.float32)
+
+
+def test_spectrogram_to_tokens_pipeline(mm, O):
+    """Waveforms -> normalised log-mel (B, 384, 128) -> tokens (B, 192, 768), both steps on the device: against the oracle's
+    patch embedding of the oracle's spectrogram, within the front-end's own tolerance carried through the projection."""
+    from multi_modal_amd.patch_embed import PatchEmbed
+    from conftest import synth
+    clips = torch.from_numpy(np.stack([synth("noise0.1", 160000, 300 + i) for i in range(3)]))
+    g = torch.Generator().manual_seed(9)
+    w = torch.randn(768, 1, 16, 16, generator=g) * 0.02
+    b = torch.randn(768, generator=g) * 0.1
+    spec = mm.preprocessing_audio_batch(clips.cuda())
+    tokens = PatchEmbed((384, 128), w, b)(spec.unsqueeze(1))
+    ref_spec = torch.stack([O.preprocessing_audio(c[None]) for c in clips])
+    ref = O.patch_embed(ref_spec, w, b, compute_dtype=torch.float16, out_dtype=torch.float64)
+    same_spec = O.patch_embed(spec.cpu(), w, b, compute_dtype=torch.float16, out_dtype=torch.float64)
+    scale = O.patch_embed(ref_spec.abs(), w.abs(), None, compute_dtype=torch.float16, out_dtype=torch.float64)
+    assert tokens.shape == (3, 192, 768)
+    assert ((tokens.cpu().double() - same_spec).abs() <= 2e-5 * scale + 1e-6).all()       # the projection itself
+    assert ((tokens.cpu().double() - ref).abs() <= 2e-3 * scale).all()                     # end to end: half-precision rounding of a 5e-4 input difference
