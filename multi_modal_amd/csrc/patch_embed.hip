@@ -62,19 +62,48 @@ struct PatchArgs {
 // One LDS-DMA: every lane's 16 bytes at `gsrc` go to LDS byte address lds_dst + 16 * lane.  M0 holds the destination base for
 // the instruction; it is the compiler's register, so it is saved and restored inside the statement.  Not counted by the
 // compiler's s_waitcnt bookkeeping: completion is waited for by hand (vmcnt, see the step loop).
+#ifndef MMFE_PE_NTLOAD
+#define MMFE_PE_NTLOAD 0      // image loads bypass the caches (tuning switch)
+#endif
+#if MMFE_PE_NTLOAD
+#define MMFE_PE_LD_HINT " nt"
+#else
+#define MMFE_PE_LD_HINT ""
+#endif
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+#ifdef MMFE_PE_NOLOAD         // ablation build: no image traffic (the arithmetic runs on whatever the buffers hold)
+    asm volatile("" : "=s"(keep) : "v"(gsrc), "s"(lds_dst));
+#else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" MMFE_PE_LD_HINT "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+#endif
 }
 
 // Token stores are inline asm so that their number per step is exactly what the step loop's vmcnt count assumes (the compiler
 // could split or merge plain stores).  The trailing s_nop keeps the data registers intact until the store has read them.
+#ifndef MMFE_PE_NT
+#define MMFE_PE_NT 0          // 1: token stores bypass the caches.  Measured slower (1.01 vs 0.66 ms per 4096 clips, float32 tokens): a store instruction
+                              // writes 64-byte halves of 16 lines, and the other halves come from the next instruction; cached, they merge in L2
+#endif
+#if MMFE_PE_NT
+#define MMFE_PE_ST_HINT " nt"
+#else
+#define MMFE_PE_ST_HINT ""
+#endif
 __device__ __forceinline__ void store16(void* p, u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+#ifdef MMFE_PE_NOSTORE        // ablation build: what the kernel takes without its token stores (results are kept alive, not written)
+    asm volatile("" :: "v"(p), "v"(v));
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off" MMFE_PE_ST_HINT "\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+#endif
 }
 __device__ __forceinline__ void store8(void* p, u32x2 v) {
-    asm volatile("global_store_dwordx2 %0, %1, off nt\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+#ifdef MMFE_PE_NOSTORE
+    asm volatile("" :: "v"(p), "v"(v));
+#else
+    asm volatile("global_store_dwordx2 %0, %1, off" MMFE_PE_ST_HINT "\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+#endif
 }
 
 template <bool BF>
@@ -91,7 +120,13 @@ __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
 
 // Number of token-store instructions a wave issues per step (4 patch groups of 16): what the vmcnt wait skips over.
 template <int NT, int OUT>
-constexpr int stores_per_step() { return 4 * (OUT == MMFE_OUT_F32 ? NT : (NT % 2 == 0 ? NT / 2 : NT)); }
+constexpr int stores_per_step() {
+#ifdef MMFE_PE_NOSTORE
+    return 0;
+#else
+    return 4 * (OUT == MMFE_OUT_F32 ? NT : (NT % 2 == 0 ? NT / 2 : NT));
+#endif
+}
 
 // NT: 16-column tiles per wave (E = 128 NT).  BF: bfloat16 (else float16) operands.  OUT: MMFE_OUT_* of the tokens.
 template <int NT, bool BF, int OUT>

@@ -2,7 +2,7 @@
 """Throughput of the secondary configurations (BASELINE.json configs[2], the EPIC parity configuration,
 configs[4] per GPU and the headline configuration fed with 16-bit PCM) on one GPU: units/s, achieved algorithmic GB/s and fraction of the 8 TB/s HBM peak.
 
-    python scripts/bench_configs.py [har] [epic] [logmel] [pcm] [resample] [--iters 20]
+    python scripts/bench_configs.py [har] [epic] [logmel] [pcm] [resample] [patch] [patch16] [tokens] [--iters 20]
 
 bench.py imports `run_config` to append the same lines to its JSON under "secondary".
 """
@@ -87,12 +87,39 @@ def run_config(name: str, dev: torch.device, iters: int = 20) -> dict:
         avg, mn = timeit(lambda: mm.resample_batch(x, 44100, 16000, out=out), iters)
         return _line("resampler 44.1 -> 16 kHz from 16-bit PCM (1024, 441000) int16 -> (1024, 160000), kernel resample",
                      "clips/s", B, 441000 * 2 + 160000 * 4, avg, mn)
+    if name in ("patch", "patch16", "tokens"):
+        # the consumer's first layer on the 4096 spectrograms of the headline configuration: (4096, 1, 384, 128) -> (4096, 192, 768)
+        from multi_modal_amd.patch_embed import PatchEmbed
+        B, E = 4096, 768
+        w = torch.randn(E, 1, 16, 16, generator=torch.Generator().manual_seed(7)) * 0.02
+        bias = torch.randn(E, generator=torch.Generator().manual_seed(8)) * 0.1
+        odt = torch.float32 if name == "patch" else torch.float16
+        pe = PatchEmbed((384, 128), w, bias, compute_dtype=torch.float16, out_dtype=odt)
+        out = torch.empty(B, 192, E, device=dev, dtype=odt)
+        flop = 2.0 * 192 * 256 * E
+        if name == "tokens":       # waveform -> spectrogram -> tokens, two launches
+            x = (0.1 * torch.randn(B, 160000, device=dev, generator=g)).clamp_(-1, 1)
+            spec = torch.empty(B, 384, 128, device=dev)
+
+            def both():
+                mm.preprocessing_audio_batch(x, out=spec)
+                pe(spec, out=out)
+            avg, mn = timeit(both, iters)
+            line = _line("VGGSound waveform -> log-mel -> float16 tokens (4096, 160000) -> (4096, 192, 768), kernels fbank512 + patch_embed",
+                         "clips/s", B, 153600 * 4 + 2 * 384 * 128 * 4 + 192 * E * 2, avg, mn)
+        else:
+            spec = torch.randn(B, 384, 128, device=dev, generator=g)
+            avg, mn = timeit(lambda: pe(spec, out=out), iters)
+            line = _line(f"patch embedding (4096, 1, 384, 128) float32 -> (4096, 192, 768) {str(odt).split('.')[-1]}, float16 products, kernel patch_embed",
+                         "clips/s", B, 384 * 128 * 4 + 192 * E * out.element_size(), avg, mn)
+        line["TFLOP/s"] = round(flop * B / (avg * 1e-3) / 1e12, 1)
+        return line
     raise ValueError(name)
 
 
 def main():
     iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 20
-    names = ("har", "epic", "logmel", "pcm", "resample")
+    names = ("har", "epic", "logmel", "pcm", "resample", "patch", "patch16", "tokens")
     which = [a for a in sys.argv[1:] if a in names] or list(names)
     dev = torch.device("cuda", 0)
     for name in which:

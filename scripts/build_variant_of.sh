@@ -11,7 +11,7 @@ mkdir -p build/$NAME
     -Iinclude -Imulti_modal_amd/csrc -Rpass-analysis=kernel-resource-usage -c ${SRCFILE:-multi_modal_amd/csrc/$SRC.hip} -o build/$NAME/$SRC.o 2> build/$NAME/remarks.txt || { grep -v remark build/$NAME/remarks.txt; exit 1; }
 B=multi_modal_amd/csrc/build
 OBJS=""
-for f in mmfe_api fbank512 stft32 dftgen rfft400 frame_stats resample; do
+for f in mmfe_api fbank512 stft32 dftgen rfft400 frame_stats resample patch_embed; do
   if [ $f = $SRC ]; then OBJS="$OBJS build/$NAME/$SRC.o"; else OBJS="$OBJS $B/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libmmfe_$NAME.so $OBJS
