@@ -185,7 +185,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="units per GPU (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true", help="multi-GPU: skip the separately timed all-gather of features")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the HAR / long-utterance / EPIC / 16-bit PCM / resampler configurations")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the HAR / long-utterance / EPIC / 16-bit PCM / resampler / patch-embedding configurations")
     ap.add_argument("--cpu-budget", type=float, default=16.0)
     ap.add_argument("--precondition", type=float, default=0.5, help="seconds of untimed launches before the warm-up steps")
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)
@@ -343,7 +343,7 @@ def main():
             try:
                 sys.path.insert(0, os.path.join(ROOT, "scripts"))
                 from bench_configs import run_config
-                res["secondary"] = [run_config(name, dev, 10) for name in ("har", "logmel", "epic", "pcm", "resample")]
+                res["secondary"] = [run_config(name, dev, 10) for name in ("har", "logmel", "epic", "pcm", "resample", "patch", "patch16")]
             except Exception as exc:  # never let a secondary configuration take the headline line down
                 res["secondary"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:

@@ -9,12 +9,13 @@ the Python call signatures of lixinghe1999/multi_modal's dataset classes.
     transforms.frame_signal          frame_signal                                 (utils/transforms.py:19-61)
     stats.cal_norm                   cal_norm                                     (vggsound.py:85-107)
     resample.load_resampled          the resampling of librosa.load(sr=16000)     (vggsound.py:114; extract_audio.py:6-13)
+    patch_embed.PatchEmbed           PatchEmbed.forward with the audio projection (models/vit_model.py:193-199, 435)
     loader.DevicePrefetcher          `batch[k].to(device)` of the training loop, overlapped    (vanilla_multi.py:76-77, 89-92)
     partition.*                      batch sharding over the GPUs of a node + all-gather of features
 
 All arithmetic runs in libmmfe.so (hand-written HIP for gfx950, C ABI in include/mmfe.h).
 """
-from . import _native, epic, har, kaldi, loader, logmel, melbank, partition, resample, stats, transforms, vggsound  # noqa: F401
+from . import _native, epic, har, kaldi, loader, logmel, melbank, partition, patch_embed, resample, stats, transforms, vggsound  # noqa: F401
 from ._native import MmfeError, library_path, load_library  # noqa: F401
 from .epic import log_specgram, log_specgram_batch, spec_to_tensor  # noqa: F401
 from .har import stft_mag  # noqa: F401

@@ -13,7 +13,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SOURCES = ("fbank512", "rfft400", "stft32", "dftgen", "resample", "frame_stats")
+SOURCES = ("fbank512", "rfft400", "stft32", "dftgen", "resample", "frame_stats", "patch_embed")
 NO_VECTORISER = ("fbank512", "resample")
 BASE = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-signed-zeros -fno-slp-vectorize -Wall -Wno-unused-function".split()
 FIELDS = (("TotalSGPRs", "sgpr"), ("VGPRs", "vgpr"), ("AGPRs", "agpr"), ("ScratchSize [bytes/lane]", "scratch_B"),
