@@ -75,3 +75,29 @@ def test_noalloc_matches_run_on_two_calls_in_a_row(mm):
     okb = big[: N.NOALLOC_MAX_ROWS]
     a6, b6 = _both(plan, okb)
     assert torch.equal(a6, b6)
+
+
+def test_noalloc_two_streams_ordered_by_events(mm):
+    """Every mmfe_run_noalloc call on a GPU uses that GPU's ONE static array, whatever plan or stream it comes from: calls with
+    clamp_below_max plans must not overlap on the device.  Two plans on two streams are fine when the second stream waits for the
+    first (the documented way to use them): each result equals mmfe_run's on its own stream."""
+    from multi_modal_amd import logmel
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(78)
+    plan_a = logmel._plan(0, 400, 160, 80, 16000, False, stream=1)      # two plans (the Python layer keeps one per stream)
+    plan_b = logmel._plan(0, 400, 160, 80, 16000, False, stream=2)
+    assert plan_a is not plan_b
+    xa = torch.randn(64, 32000, device=dev, generator=g) * torch.logspace(-3, 0, 64, device=dev)[:, None]
+    xb = 0.05 * torch.randn(33, 24000, device=dev, generator=g)
+    ref_a, _ = _both(plan_a, xa)
+    ref_b, _ = _both(plan_b, xb)
+    sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    out_a, out_b = torch.empty_like(ref_a), torch.empty_like(ref_b)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        plan_a.run_noalloc_ptr(xa.data_ptr(), xa.stride(0), xa.shape[0], xa.shape[1], out_a.data_ptr(), sa.cuda_stream)
+        sb.wait_stream(sa)                                              # the second call starts after the first has finished
+        plan_b.run_noalloc_ptr(xb.data_ptr(), xb.stride(0), xb.shape[0], xb.shape[1], out_b.data_ptr(), sb.cuda_stream)
+        sa.wait_stream(sb)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, ref_a) and torch.equal(out_b, ref_b)
