@@ -213,12 +213,35 @@ def case_har_batch(rng):
     return f"harbatch[{mm.plans.last_kernel()}] {shape} noverlap={nov}", mx, p, mx <= 1e-6
 
 
+_patch_objs = {}
+
+
+def case_patch(rng):
+    """Patch embedding on dyadic data (the float32 convolution has one right answer): random image sizes, batch sizes that end in
+    partial steps, both embedding sizes, both 16-bit product types and every token type; exact."""
+    from multi_modal_amd.patch_embed import PatchEmbed
+    H = int(rng.integers(16, 200))
+    W = 4 * int(rng.integers(4, 50))
+    E = int(rng.choice([384, 768]))
+    B = int(rng.integers(1, 40))
+    compute = [torch.float16, torch.bfloat16][int(rng.integers(2))]
+    out_dtype = [torch.float32, torch.float16, torch.bfloat16][int(rng.integers(3))]
+    x = torch.from_numpy(rng.integers(-12, 13, size=(B, 1, H, W)).astype(np.float32) / 4.0)
+    w = torch.from_numpy(rng.integers(-8, 9, size=(E, 1, 16, 16)).astype(np.float32) / 16.0)
+    b = torch.from_numpy(rng.integers(-64, 65, size=(E,)).astype(np.float32) / 8.0)
+    ref = O.patch_embed(x, w, b, compute_dtype=None).to(out_dtype)
+    got = PatchEmbed((H, W), w, b, compute_dtype=compute, out_dtype=out_dtype)(x.cuda()).cpu()
+    assert got.shape == ref.shape and got.dtype == ref.dtype, (got.shape, ref.shape)
+    mx, p = stats((got.double() - ref.double()).numpy())
+    return f"patch B={B} {H}x{W} E={E} {compute} -> {out_dtype}", mx, p, mx == 0.0
+
+
 def main():
     cases = int(sys.argv[sys.argv.index("--cases") + 1]) if "--cases" in sys.argv else 200
     seed = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 0
     rng = np.random.default_rng(seed)
     makers = [case_fbank, case_fbank, case_logmel, case_logmel, case_har, case_frame, case_epic, case_half, case_pcm, case_logspec, case_logspec,
-              case_resample, case_resample, case_logmel_batch, case_har_batch]
+              case_resample, case_resample, case_logmel_batch, case_har_batch, case_patch]
     worst = {}
     for i in range(cases):
         fn = makers[i % len(makers)]
