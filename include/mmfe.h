@@ -243,20 +243,22 @@ const char* mmfe_plan_kernel(const mmfe_plan* plan);
  * computed under @autocast() (vit_model.py:388) in a 16-bit type.  mmfe_patch_embed_create packs Conv2d.weight
  * ((embed_dim, 1, 16, 16) contiguous = embed_dim rows of 256 floats) and Conv2d.bias (embed_dim floats or NULL), rounded to
  * compute_dtype (MMFE_OUT_F16: what autocast uses on a GPU; MMFE_OUT_BF16), into matrix-pipe operand order on `device`;
- * the image is rounded to compute_dtype on the way in, products are accumulated in float32, tokens are stored as out_dtype.
- * Limits: patch = 16, embed_dim 384 or 768, width a multiple of 4; rows / columns beyond the last whole patch are ignored,
- * as the convolution ignores them. */
+ * the image (in_dtype MMFE_IN_F32) is rounded to compute_dtype on the way in, or already holds that type (in_dtype MMFE_IN_F16 /
+ * MMFE_IN_BF16: the spectrogram as the front-end kernels store it with out_dtype float16 / bfloat16, bit-identical to the cast);
+ * products are accumulated in float32, tokens are stored as out_dtype.
+ * Limits: patch = 16, embed_dim 384 or 768, width a multiple of 4 (8 for 16-bit images); rows / columns beyond the last whole
+ * patch are ignored, as the convolution ignores them. */
 typedef struct mmfe_patch_embed mmfe_patch_embed;
 int mmfe_patch_embed_create(int32_t height, int32_t width, int32_t patch, int32_t embed_dim, const float* weight, const float* bias,
-                            int32_t compute_dtype, int32_t out_dtype, int device, mmfe_patch_embed** out_handle);
+                            int32_t in_dtype, int32_t compute_dtype, int32_t out_dtype, int device, mmfe_patch_embed** out_handle);
 int mmfe_patch_embed_destroy(mmfe_patch_embed* handle);
 /* P and embed_dim of the tokens one image yields. */
 int mmfe_patch_embed_shape(const mmfe_patch_embed* handle, int64_t* n_patches, int64_t* embed_dim);
-/* x: device, n_batch float32 images of height x width (unit column stride, row stride = width), image b starting
+/* x: device, n_batch images (elements of in_dtype) of height x width (unit column stride, row stride = width), image b starting
  * x_batch_stride elements after image b - 1 (16-byte aligned); out: device, (n_batch, P, embed_dim) of out_dtype, image b's
  * tokens starting out_batch_stride elements after image b - 1's (so that a caller can leave room for a class token in
  * front, vit_model.py:382-383).  Asynchronous on hip_stream, allocates nothing. */
-int mmfe_patch_embed_run(const mmfe_patch_embed* handle, const float* x, int64_t x_batch_stride, int64_t n_batch, void* out,
+int mmfe_patch_embed_run(const mmfe_patch_embed* handle, const void* x, int64_t x_batch_stride, int64_t n_batch, void* out,
                          int64_t out_batch_stride, void* hip_stream);
 
 #ifdef __cplusplus

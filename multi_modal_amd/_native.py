@@ -119,7 +119,7 @@ def bind_library(path: str):
     lib.mmfe_plan_kernel.argtypes = [ctypes.c_void_p]
     lib.mmfe_patch_embed_create.restype = ctypes.c_int
     lib.mmfe_patch_embed_create.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
-                                            ctypes.c_int32, ctypes.c_int32, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+                                            ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
     lib.mmfe_patch_embed_destroy.restype = ctypes.c_int
     lib.mmfe_patch_embed_destroy.argtypes = [ctypes.c_void_p]
     lib.mmfe_patch_embed_shape.restype = ctypes.c_int
@@ -254,7 +254,7 @@ class PatchEmbedHandle:
     """Owns one mmfe_patch_embed (the 16 x 16 / stride-16 patch convolution's weights in matrix-pipe operand order on one device)."""
 
     def __init__(self, height: int, width: int, weight: np.ndarray, bias: Optional[np.ndarray], compute_dtype: int, out_dtype: int,
-                 device: int = 0, patch: int = 16):
+                 device: int = 0, patch: int = 16, in_dtype: int = IN_F32):
         self._lib = load_library()
         w = np.ascontiguousarray(weight, dtype=np.float32)
         if w.ndim != 2 or w.shape[1] != patch * patch:
@@ -264,7 +264,7 @@ class PatchEmbedHandle:
             raise ValueError(f"bias must have {w.shape[0]} entries, got {b.shape}")
         handle = ctypes.c_void_p()
         check(self._lib.mmfe_patch_embed_create(int(height), int(width), int(patch), int(w.shape[0]), w.ctypes.data_as(ctypes.c_void_p),
-                                                None if b is None else b.ctypes.data_as(ctypes.c_void_p), int(compute_dtype),
+                                                None if b is None else b.ctypes.data_as(ctypes.c_void_p), int(in_dtype), int(compute_dtype),
                                                 int(out_dtype), int(device), ctypes.byref(handle)), "mmfe_patch_embed_create")
         self._handle = handle
         self.device = int(device)

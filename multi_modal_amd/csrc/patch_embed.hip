@@ -45,10 +45,14 @@ constexpr int kThreads = 64 * kWaves;
 constexpr int kTileM = 64;                 // patches per block step
 constexpr int kRowBytes = kK * 4 + 16;     // LDS row of one patch: 1 KB of float32 + 16 bytes (bank spreading)
 constexpr int kBufBytes = kTileM * kRowBytes;
+// 16-bit images: a patch is 512 bytes, one DMA brings a PAIR of patches with their 16-byte pieces interleaved (piece c of the even
+// patch at 32 c, of the odd patch at 32 c + 16); pairs are 1056 bytes apart, which puts patch m's piece on bank group (m + 2 s) mod 16
+constexpr int kPairBytes = 2 * kK * 2 + 32;
+constexpr int kBuf16Bytes = (kTileM / 2) * kPairBytes;
 constexpr int kBiasBytes = 4096;           // E <= 768 floats, padded
 
 struct PatchArgs {
-    const float* x;            // (B, H, W) float32
+    const void* x;             // (B, H, W) float32, or the 16-bit type of the products
     int64_t x_batch_stride;    // elements
     const u32x4* wpack;        // MFMA operand order: [(wave * NT + tile)][step][lane] 16 bytes (8 values of the 16-bit type)
     const float* bias;         // E floats (zeros when the layer has no bias)
@@ -129,7 +133,8 @@ constexpr int stores_per_step() {
 }
 
 // NT: 16-column tiles per wave (E = 128 NT).  BF: bfloat16 (else float16) operands.  OUT: MMFE_OUT_* of the tokens.
-template <int NT, bool BF, int OUT>
+// IN16: the image already holds the 16-bit type of the products (what the front-end kernels store with out_dtype float16 / bfloat16).
+template <int NT, bool BF, int OUT, bool IN16>
 __global__ void __launch_bounds__(kThreads) patch_embed_kernel(const PatchArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // the one LDS object: [bias 4 KB][buffer 0][buffer 1]
     const int lane = threadIdx.x & 63;
@@ -145,22 +150,41 @@ __global__ void __launch_bounds__(kThreads) patch_embed_kernel(const PatchArgs p
         for (int s = 0; s < 8; ++s) wf[t][s] = p.wpack[((size_t)(wave * NT + t) * 8 + s) * 64 + lane];
     for (int i = threadIdx.x; i < kBiasBytes / 4; i += kThreads) reinterpret_cast<float*>(smem)[i] = i < p.E ? p.bias[i] : 0.f;
 
-    // lane part of a patch's source address: piece `lane` of the 64 sixteen-byte pieces is image row lane >> 2, columns 4 (lane & 3)..+3
-    const int64_t lane_off = (int64_t)(lane >> 2) * p.W + 4 * (lane & 3);
+    // lane part of a patch's source address.  float32: piece `lane` of the 64 sixteen-byte pieces is image row lane >> 2, columns
+    // 4 (lane & 3)..+3.  16-bit: lane = 2 c + e fetches piece c (image row c >> 1, columns 8 (c & 1)..+7) of the pair's patch e.
+    const int64_t lane_off = IN16 ? (int64_t)(lane >> 2) * p.W + 8 * ((lane >> 1) & 1) : (int64_t)(lane >> 2) * p.W + 4 * (lane & 3);
     const int Ph = p.P / p.Pw;
+    constexpr int kBuf = IN16 ? kBuf16Bytes : kBufBytes;
     auto stage = [&](int tile, int buf) {           // request the 64 patches of step `tile` into buffer `buf`: 8 consecutive ones per wave
         unsigned m = (unsigned)tile * kTileM + wave * (kTileM / kWaves);
         if ((int64_t)m > p.M - 1) m = (unsigned)(p.M - 1);           // a last, partial step: waves beyond the batch re-read its last patch
         unsigned b = m / (unsigned)p.P;
         unsigned pp = m - b * (unsigned)p.P;
         int ph = (int)(pp / (unsigned)p.Pw), pw = (int)(pp - (pp / (unsigned)p.Pw) * (unsigned)p.Pw);
-#pragma unroll
-        for (int r = 0; r < kTileM / kWaves; ++r) {
-            const int ml = wave * (kTileM / kWaves) + r;
-            const float* src = p.x + (int64_t)b * p.x_batch_stride + (int64_t)(ph * kPatch) * p.W + pw * kPatch + lane_off;
-            dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + kBiasBytes + buf * kBufBytes + ml * kRowBytes)));
-            if ((int64_t)m + r + 1 < p.M) {                          // a last, partial step re-reads the last patch (never stored)
+        auto patch_base = [&]() { return (int64_t)b * p.x_batch_stride + (int64_t)(ph * kPatch) * p.W + pw * kPatch; };
+        auto advance = [&](int r) {                                  // to the next patch (a last, partial step stays on the last one)
+            if ((int64_t)m + r + 1 < p.M) {
                 if (++pw == p.Pw) { pw = 0; if (++ph == Ph) { ph = 0; ++b; } }
+            }
+        };
+        if constexpr (!IN16) {
+#pragma unroll
+            for (int r = 0; r < kTileM / kWaves; ++r) {
+                const int ml = wave * (kTileM / kWaves) + r;
+                const float* src = static_cast<const float*>(p.x) + patch_base() + lane_off;
+                dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + kBiasBytes + buf * kBuf + ml * kRowBytes)));
+                advance(r);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < kTileM / kWaves; r += 2) {
+                const int pair = (wave * (kTileM / kWaves) + r) >> 1;
+                const int64_t base0 = patch_base();
+                advance(r);
+                const int64_t base1 = patch_base();
+                advance(r + 1);
+                const unsigned short* src = static_cast<const unsigned short*>(p.x) + ((lane & 1) ? base1 : base0) + lane_off;
+                dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + kBiasBytes + buf * kBuf + pair * kPairBytes)));
             }
         }
     };
@@ -184,7 +208,7 @@ __global__ void __launch_bounds__(kThreads) patch_embed_kernel(const PatchArgs p
         const int next = tile + gridDim.x;
         if (next < p.n_tiles) stage(next, buf ^ 1);
 
-        const char* tile_base = smem + kBiasBytes + buf * kBufBytes;
+        const char* tile_base = smem + kBiasBytes + buf * kBuf;
 #pragma unroll 1
         for (int mt = 0; mt < 4; ++mt) {
             f32x4 acc[NT];
@@ -195,14 +219,24 @@ __global__ void __launch_bounds__(kThreads) patch_embed_kernel(const PatchArgs p
                 else c = col0 + 32 * (t >> 1) + 8 * lh + 4 * (t & 1);
                 acc[t] = *reinterpret_cast<const f32x4*>(smem + 4 * c);
             }
-            const char* row = tile_base + (mt * 16 + lm) * kRowBytes + lh * 256;
+            if constexpr (IN16) {
+                const char* row = tile_base + ((mt * 16 + lm) >> 1) * kPairBytes + (lm & 1) * 16 + lh * 256;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(row + 32 * s);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(row + 32 * s + 16);
-                const u32x4 b = to16<BF>(f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w});
+                for (int s = 0; s < 8; ++s) {
+                    const u32x4 b = *reinterpret_cast<const u32x4*>(row + 32 * s);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = mfma<BF>(wf[t][s], b, acc[t]);
+                    for (int t = 0; t < NT; ++t) acc[t] = mfma<BF>(wf[t][s], b, acc[t]);
+                }
+            } else {
+                const char* row = tile_base + (mt * 16 + lm) * kRowBytes + lh * 256;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(row + 32 * s);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(row + 32 * s + 16);
+                    const u32x4 b = to16<BF>(f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w});
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = mfma<BF>(wf[t][s], b, acc[t]);
+                }
             }
             // epilogue: lane (lm, lh) holds, per tile t, 4 output columns of patch mt * 16 + lm.  The float32 stores read the
             // accumulators from inside asm statements, where the compiler pads no hazards: the wait states a vector-memory read of
@@ -264,10 +298,15 @@ unsigned short host_f16(float v) {
 }
 
 typedef void (*kernel_fn)(const PatchArgs);
+template <int NT, bool BF, bool IN16>
+kernel_fn pick_out(int out) {
+    return out == MMFE_OUT_F32 ? &patch_embed_kernel<NT, BF, MMFE_OUT_F32, IN16> : out == MMFE_OUT_F16 ? &patch_embed_kernel<NT, BF, MMFE_OUT_F16, IN16>
+                                                                                                       : &patch_embed_kernel<NT, BF, MMFE_OUT_BF16, IN16>;
+}
 template <int NT>
-kernel_fn pick_kernel(bool bf, int out) {
-    if (bf) return out == MMFE_OUT_F32 ? &patch_embed_kernel<NT, true, MMFE_OUT_F32> : out == MMFE_OUT_F16 ? &patch_embed_kernel<NT, true, MMFE_OUT_F16> : &patch_embed_kernel<NT, true, MMFE_OUT_BF16>;
-    return out == MMFE_OUT_F32 ? &patch_embed_kernel<NT, false, MMFE_OUT_F32> : out == MMFE_OUT_F16 ? &patch_embed_kernel<NT, false, MMFE_OUT_F16> : &patch_embed_kernel<NT, false, MMFE_OUT_BF16>;
+kernel_fn pick_kernel(bool bf, int out, bool in16) {
+    if (bf) return in16 ? pick_out<NT, true, true>(out) : pick_out<NT, true, false>(out);
+    return in16 ? pick_out<NT, false, true>(out) : pick_out<NT, false, false>(out);
 }
 
 }  // namespace
@@ -276,6 +315,7 @@ struct PatchEmbed {
     int device = -1;
     int height = 0, width = 0, embed = 0, nt = 0;
     int compute = MMFE_OUT_BF16, out_dtype = MMFE_OUT_F32;
+    bool in16 = false;
     u32x4* d_wpack = nullptr;
     float* d_bias = nullptr;
     kernel_fn fn = nullptr;
@@ -288,13 +328,16 @@ using namespace mmfe;
 extern "C" {
 
 int mmfe_patch_embed_create(int32_t height, int32_t width, int32_t patch, int32_t embed_dim, const float* weight, const float* bias,
-                            int32_t compute_dtype, int32_t out_dtype, int device, mmfe_patch_embed** out_handle) {
+                            int32_t in_dtype, int32_t compute_dtype, int32_t out_dtype, int device, mmfe_patch_embed** out_handle) {
     if (out_handle == nullptr) { set_error("out_handle is NULL"); return MMFE_EINVAL; }
     *out_handle = nullptr;
     if (weight == nullptr) { set_error("weight is NULL"); return MMFE_EINVAL; }
     if (patch != kPatch) { set_error("patch_embed: the kernel is built for 16 x 16 patches with stride 16 (vit_model.py:435), got %d", patch); return MMFE_EINVAL; }
     if (height < kPatch || width < kPatch) { set_error("patch_embed: image %d x %d smaller than one patch", height, width); return MMFE_EINVAL; }
-    if (width % 4 != 0) { set_error("patch_embed: image width must be a multiple of 4 (16-byte pieces), got %d", width); return MMFE_EINVAL; }
+    if (in_dtype != MMFE_IN_F32 && in_dtype != MMFE_IN_F16 && in_dtype != MMFE_IN_BF16) { set_error("patch_embed: in_dtype is MMFE_IN_F32, MMFE_IN_F16 or MMFE_IN_BF16"); return MMFE_EINVAL; }
+    const bool in16 = in_dtype != MMFE_IN_F32;
+    if (in16 && (in_dtype == MMFE_IN_F16) != (compute_dtype == MMFE_OUT_F16)) { set_error("patch_embed: a 16-bit image must hold the type of the products (compute_dtype)"); return MMFE_EINVAL; }
+    if (width % (in16 ? 8 : 4) != 0) { set_error("patch_embed: image width must be a multiple of %d (16-byte pieces), got %d", in16 ? 8 : 4, width); return MMFE_EINVAL; }
     if (embed_dim != 384 && embed_dim != 768) { set_error("patch_embed: embed_dim 384 or 768 (8 waves x 3 or 6 tiles of 16 columns), got %d", embed_dim); return MMFE_EINVAL; }
     if (compute_dtype != MMFE_OUT_F16 && compute_dtype != MMFE_OUT_BF16) { set_error("patch_embed: compute_dtype is MMFE_OUT_F16 or MMFE_OUT_BF16"); return MMFE_EINVAL; }
     if (out_dtype < MMFE_OUT_F32 || out_dtype > MMFE_OUT_BF16) { set_error("patch_embed: unknown out_dtype"); return MMFE_EINVAL; }
@@ -305,7 +348,7 @@ int mmfe_patch_embed_create(int32_t height, int32_t width, int32_t patch, int32_
     PatchEmbed* pe = new (std::nothrow) PatchEmbed();
     if (pe == nullptr) { set_error("out of host memory"); return MMFE_ENOMEM; }
     pe->device = device; pe->height = height; pe->width = width; pe->embed = embed_dim; pe->nt = embed_dim / 128;
-    pe->compute = compute_dtype; pe->out_dtype = out_dtype;
+    pe->compute = compute_dtype; pe->out_dtype = out_dtype; pe->in16 = in16;
     const int NT = pe->nt;
     const bool bf = compute_dtype == MMFE_OUT_BF16;
     const bool paired = out_dtype != MMFE_OUT_F32 && NT % 2 == 0;
@@ -338,7 +381,7 @@ int mmfe_patch_embed_create(int32_t height, int32_t width, int32_t patch, int32_
         set_error("patch_embed: uploading the weights failed");
         rc = MMFE_EHIP;
     }
-    if (rc == MMFE_OK) pe->fn = NT == 6 ? pick_kernel<6>(bf, out_dtype) : pick_kernel<3>(bf, out_dtype);
+    if (rc == MMFE_OK) pe->fn = NT == 6 ? pick_kernel<6>(bf, out_dtype, in16) : pick_kernel<3>(bf, out_dtype, in16);
     if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     if (rc) { (void)hipFree(pe->d_wpack); (void)hipFree(pe->d_bias); delete pe; return rc; }
     *out_handle = reinterpret_cast<mmfe_patch_embed*>(pe);
@@ -365,7 +408,7 @@ int mmfe_patch_embed_shape(const mmfe_patch_embed* handle, int64_t* n_patches, i
     return MMFE_OK;
 }
 
-int mmfe_patch_embed_run(const mmfe_patch_embed* handle, const float* x, int64_t x_batch_stride, int64_t n_batch, void* out,
+int mmfe_patch_embed_run(const mmfe_patch_embed* handle, const void* x, int64_t x_batch_stride, int64_t n_batch, void* out,
                          int64_t out_batch_stride, void* hip_stream) {
     const PatchEmbed* pe = reinterpret_cast<const PatchEmbed*>(handle);
     if (pe == nullptr) { set_error("handle is NULL"); return MMFE_EINVAL; }
@@ -376,14 +419,14 @@ int mmfe_patch_embed_run(const mmfe_patch_embed* handle, const float* x, int64_t
     const int64_t P = (int64_t)Ph * Pw;
     if (x_batch_stride < (int64_t)pe->height * pe->width && n_batch > 1) { set_error("x_batch_stride smaller than one image"); return MMFE_EINVAL; }
     if (out_batch_stride < P * pe->embed && n_batch > 1) { set_error("out_batch_stride smaller than one image's tokens"); return MMFE_EINVAL; }
-    if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (x_batch_stride & 3) != 0) { set_error("patch_embed: images must start on 16-byte boundaries"); return MMFE_EINVAL; }
+    if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (x_batch_stride & (pe->in16 ? 7 : 3)) != 0) { set_error("patch_embed: images must start on 16-byte boundaries"); return MMFE_EINVAL; }
     const int esz = pe->out_dtype == MMFE_OUT_F32 ? 4 : 2;
     if ((reinterpret_cast<uintptr_t>(out) & 15) != 0 || (out_batch_stride * esz) % 16 != 0) { set_error("patch_embed: token rows must start on 16-byte boundaries"); return MMFE_EINVAL; }
     const int64_t M = n_batch * P;
     if (M > 0x7fffff00ll) { set_error("patch_embed: batch too large"); return MMFE_EINVAL; }
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess || (prev != pe->device && hipSetDevice(pe->device) != hipSuccess)) { set_error("cannot make device %d current", pe->device); return MMFE_EHIP; }
-    const size_t lds = kBiasBytes + 2 * kBufBytes;
+    const size_t lds = kBiasBytes + 2 * (pe->in16 ? kBuf16Bytes : kBufBytes);
     int blocks_per_cu = 1, cus = 256;
     int rc = kernel_prepare(reinterpret_cast<const void*>(pe->fn), kThreads, lds, &blocks_per_cu, &cus);
     if (rc == MMFE_OK) {

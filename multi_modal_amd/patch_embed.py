@@ -48,13 +48,26 @@ class PatchEmbed:
         b = None if bias is None else bias.detach().to("cpu", torch.float32).numpy()
         self.device = torch.cuda.current_device() if device is None else int(device)
         self.out_dtype = out_dtype
-        self._h = N.PatchEmbedHandle(self.img_size[0], self.img_size[1], w.contiguous().numpy(), b, _COMPUTE[compute_dtype],
-                                     OUT_CODES[out_dtype], device=self.device)
-        self.num_patches = self._h.n_patches
-        self.embed_dim = self._h.embed_dim
+        self.compute_dtype = compute_dtype
+        self._w, self._b = w.contiguous().numpy(), b
+        self._handles = {}                       # one per image dtype: float32 (rounded on the way in) or the products' own 16-bit type
+        h = self._handle(torch.float32)
+        self.num_patches = h.n_patches
+        self.embed_dim = h.embed_dim
+
+    def _handle(self, in_dtype: torch.dtype) -> N.PatchEmbedHandle:
+        h = self._handles.get(in_dtype)
+        if h is None:
+            code = {torch.float32: N.IN_F32, torch.float16: N.IN_F16, torch.bfloat16: N.IN_BF16}[in_dtype]
+            h = N.PatchEmbedHandle(self.img_size[0], self.img_size[1], self._w, self._b, _COMPUTE[self.compute_dtype],
+                                   OUT_CODES[self.out_dtype], device=self.device, in_dtype=code)
+            self._handles[in_dtype] = h
+        return h
 
     def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """x: (B, 1, H, W) or (B, H, W) float32 on this object's GPU (a CPU tensor is copied over and the tokens copied back).
+        """x: (B, 1, H, W) or (B, H, W) on this object's GPU (a CPU tensor is copied over and the tokens copied back), float32 - rounded
+        to compute_dtype on the way into the matrix pipe - or already of compute_dtype (the spectrogram as
+        `preprocessing_audio_batch(dtype=...)` stores it: the same values, half the bytes); any other dtype is cast to float32 first.
         out, when given: a (B, T, E) tensor of out_dtype with T >= num_patches whose LAST num_patches token rows are written
         (T = num_patches + 1 leaves row 0 for the class token that vit_model.py:382-383 concatenates in front)."""
         origin = x.device
@@ -64,12 +77,14 @@ class PatchEmbed:
             x = x[:, 0]
         if x.dim() != 3 or tuple(x.shape[1:]) != self.img_size:
             raise ValueError(f"expected (B, {self.img_size[0]}, {self.img_size[1]}) images, got {tuple(x.shape)}")
-        if x.dtype != torch.float32:
+        if x.dtype != torch.float32 and not (x.dtype == self.compute_dtype and self.img_size[1] % 8 == 0):
             x = x.to(torch.float32)
         if not x.is_cuda:
             x = x.cuda(self.device)
-        if x.stride(2) != 1 or x.stride(1) != x.shape[2] or x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0:
+        if x.stride(2) != 1 or x.stride(1) != x.shape[2] or x.stride(0) % 8 != 0 or x.data_ptr() % 16 != 0:
             x = x.contiguous()
+        if x.data_ptr() % 16 != 0:
+            x = x.clone()
         B = x.shape[0]
         P, E = self.num_patches, self.embed_dim
         if out is None:
@@ -82,11 +97,13 @@ class PatchEmbed:
             first = out.shape[1] - P
         if B > 0:
             stream = torch.cuda.current_stream(x.device).cuda_stream
-            self._h.run_ptr(x.data_ptr(), x.stride(0) if B > 1 else x[0].numel(), B, out.data_ptr() + first * E * out.element_size(),
+            self._handle(x.dtype).run_ptr(x.data_ptr(), x.stride(0) if B > 1 else x[0].numel(), B, out.data_ptr() + first * E * out.element_size(),
                             out.stride(0) if B > 1 else out[0].numel(), stream)
         return out if origin.type == "cuda" else out.to(origin)
 
     forward = __call__
 
     def close(self) -> None:
-        self._h.close()
+        for h in self._handles.values():
+            h.close()
+        self._handles.clear()

@@ -97,16 +97,16 @@ def run_config(name: str, dev: torch.device, iters: int = 20) -> dict:
         pe = PatchEmbed((384, 128), w, bias, compute_dtype=torch.float16, out_dtype=odt)
         out = torch.empty(B, 192, E, device=dev, dtype=odt)
         flop = 2.0 * 192 * 256 * E
-        if name == "tokens":       # waveform -> spectrogram -> tokens, two launches
+        if name == "tokens":       # waveform -> float16 spectrogram -> float16 tokens, two launches
             x = (0.1 * torch.randn(B, 160000, device=dev, generator=g)).clamp_(-1, 1)
-            spec = torch.empty(B, 384, 128, device=dev)
+            spec = torch.empty(B, 384, 128, device=dev, dtype=torch.float16)
 
             def both():
-                mm.preprocessing_audio_batch(x, out=spec)
+                mm.preprocessing_audio_batch(x, out=spec, dtype=torch.float16)
                 pe(spec, out=out)
             avg, mn = timeit(both, iters)
-            line = _line("VGGSound waveform -> log-mel -> float16 tokens (4096, 160000) -> (4096, 192, 768), kernels fbank512 + patch_embed",
-                         "clips/s", B, 153600 * 4 + 2 * 384 * 128 * 4 + 192 * E * 2, avg, mn)
+            line = _line("VGGSound waveform -> float16 log-mel -> float16 tokens (4096, 160000) -> (4096, 192, 768), kernels fbank512 + patch_embed",
+                         "clips/s", B, 153600 * 4 + 2 * 384 * 128 * 2 + 192 * E * 2, avg, mn)
         else:
             spec = torch.randn(B, 384, 128, device=dev, generator=g)
             avg, mn = timeit(lambda: pe(spec, out=out), iters)

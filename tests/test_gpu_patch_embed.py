@@ -98,6 +98,36 @@ def test_patch_embed_random_against_oracle(mm, O, compute, E):
     assert ((y - plain).abs() <= 2.5 * torch.finfo(compute).eps * scale + 1e-4).all()
 
 
+@pytest.mark.parametrize("compute", [torch.float16, torch.bfloat16])
+def test_patch_embed_16_bit_images(mm, O, compute):
+    """An image that already holds the products' 16-bit type (what the front-end kernels store with dtype=float16 / bfloat16) gives
+    the tokens of its float32 form bit for bit - the rounding on the way in is the identity on such values - over 900 steps
+    (pairs of patches per DMA, interleaved pieces), on a batch that ends in a partial step, and from the front-end's own output."""
+    from multi_modal_amd.patch_embed import PatchEmbed
+    g = torch.Generator().manual_seed(21)
+    w = torch.randn(768, 1, 16, 16, generator=g) * 0.03
+    b = torch.randn(768, generator=g) * 0.1
+    for B, H, W, out_dtype in ((300, 384, 128, torch.float32), (5, 48, 40, compute), (3, 128, 384, torch.float16)):
+        x16 = (torch.randn(B, 1, H, W, generator=g) * 1.5 - 0.3).to(compute).cuda()
+        pe = PatchEmbed((H, W), w, b, compute_dtype=compute, out_dtype=out_dtype)
+        y16 = pe(x16)
+        y32 = pe(x16.float())
+        assert y16.shape == (B, (H // 16) * (W // 16), 768) and torch.equal(y16, y32)
+    ref = O.patch_embed(x16.cpu().float(), w, b, compute_dtype=compute, out_dtype=torch.float64)
+    assert ((y16.cpu().double() - ref).abs() <= 2e-3 * ref.abs() + 1e-3).all()
+    # dyadic data: exact whatever the path
+    xd, wd, bd = dyadic(70, 64, 48, 384, 33)
+    refd = O.patch_embed(xd, wd, bd, compute_dtype=None)
+    assert torch.equal(PatchEmbed((64, 48), wd, bd, compute_dtype=compute)(xd.to(compute).cuda()).cpu(), refd)
+    # the front-end's 16-bit spectrogram straight into the projection
+    from conftest import synth
+    clips = torch.from_numpy(np.stack([synth("noise0.1", 160000, 400 + i) for i in range(2)])).cuda()
+    spec16 = mm.preprocessing_audio_batch(clips, dtype=compute)
+    spec32 = mm.preprocessing_audio_batch(clips)
+    pe = PatchEmbed((384, 128), w, b, compute_dtype=compute, out_dtype=compute)
+    assert spec16.dtype == compute and torch.equal(pe(spec16), pe(spec32))
+
+
 def test_patch_embed_out_with_class_token_row_and_strided_batch(mm, O):
     """`out` one row longer than the patches: row 0 is left for the class token (vit_model.py:382-383); images taken from a
     larger buffer (batch stride > H * W); a CPU tensor goes over and comes back."""
