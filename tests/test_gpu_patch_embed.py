@@ -181,3 +181,60 @@ def test_spectrogram_to_tokens_pipeline(mm, O):
     assert tokens.shape == (3, 192, 768)
     assert ((tokens.cpu().double() - same_spec).abs() <= 2e-5 * scale + 1e-6).all()       # the projection itself
     assert ((tokens.cpu().double() - ref).abs() <= 2e-3 * scale).all()                     # end to end: half-precision rounding of a 5e-4 input difference
+
+
+def test_waveform_to_tokens_in_one_hip_graph_and_from_threads(mm, O):
+    """Neither launch allocates or synchronises: the two-kernel chain waveform -> float16 spectrogram -> float16 tokens is recorded into ONE
+    HIP graph after a warm-up call and replayed on new data; and one PatchEmbed object serves four host threads on four streams."""
+    import threading
+    from multi_modal_amd.patch_embed import PatchEmbed
+    g = torch.Generator(device="cuda").manual_seed(3)
+    w = torch.randn(768, 1, 16, 16, generator=torch.Generator().manual_seed(4)) * 0.03
+    pe = PatchEmbed((384, 128), w, None, compute_dtype=torch.float16, out_dtype=torch.float16)
+    x = 0.1 * torch.randn(6, 160000, device="cuda", generator=g)
+    spec = torch.empty(6, 384, 128, device="cuda", dtype=torch.float16)
+    tokens = torch.empty(6, 193, 768, device="cuda", dtype=torch.float16)
+
+    def chain():
+        mm.preprocessing_audio_batch(x, out=spec, dtype=torch.float16)
+        pe(spec, out=tokens)
+
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        chain()
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            chain()
+    torch.cuda.current_stream().wait_stream(side)
+    x.copy_(torch.roll(x, 11, dims=-1) * 0.7)
+    want = pe(mm.preprocessing_audio_batch(x, dtype=torch.float16)).clone()
+    tokens.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(tokens[:, 1:], want) and bool((tokens[:, 0] == 0).all())
+
+    imgs = [torch.randn(40, 384, 128, device="cuda", generator=g) for _ in range(4)]
+    serial = [pe(im) for im in imgs]
+    torch.cuda.synchronize()
+    got, errs = [None] * 4, []
+
+    def work(t):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(20):
+                    y = pe(imgs[t])
+                s.synchronize()
+            got[t] = y
+        except Exception as e:
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errs, errs
+    assert all(torch.equal(got[t], serial[t]) for t in range(4))
