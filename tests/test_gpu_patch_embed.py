@@ -238,3 +238,24 @@ def test_waveform_to_tokens_in_one_hip_graph_and_from_threads(mm, O):
         th.join()
     assert not errs, errs
     assert all(torch.equal(got[t], serial[t]) for t in range(4))
+
+
+def test_epic_spectrogram_to_tokens_pipeline(mm, O):
+    """EPIC: 1.278 s slices -> log spectrogram / 255, (B, 256, 256) -> the `audio.view(-1, 1, 256, 256)` of
+    classification/vggsound/models/mbt.py:74 -> 256 tokens, both steps on the device, against the oracle's chain."""
+    from multi_modal_amd.patch_embed import PatchEmbed
+    from conftest import synth
+    x = np.stack([synth("noise0.1", 30672, 500 + i) for i in range(3)])
+    g = torch.Generator().manual_seed(19)
+    w = torch.randn(768, 1, 16, 16, generator=g) * 0.05
+    b = torch.randn(768, generator=g) * 0.1
+    spec = mm.log_specgram_batch(torch.from_numpy(x).cuda(), div255=True)
+    assert spec.shape == (3, 256, 256)
+    tokens = PatchEmbed((256, 256), w, b)(spec.view(-1, 1, 256, 256))
+    ref_spec = torch.stack([O.spec_to_tensor(O.log_specgram(xi))[0] for xi in x])
+    ref = O.patch_embed(ref_spec, w, b, compute_dtype=torch.float16, out_dtype=torch.float64)
+    same = O.patch_embed(spec.cpu(), w, b, compute_dtype=torch.float16, out_dtype=torch.float64)
+    scale = O.patch_embed(ref_spec.abs(), w.abs(), None, compute_dtype=torch.float16, out_dtype=torch.float64)
+    assert tokens.shape == (3, 256, 768)
+    assert ((tokens.cpu().double() - same).abs() <= 2e-5 * scale + 1e-6).all()
+    assert ((tokens.cpu().double() - ref).abs() <= 2e-3 * scale + 1e-5).all()
