@@ -343,7 +343,7 @@ def main():
             try:
                 sys.path.insert(0, os.path.join(ROOT, "scripts"))
                 from bench_configs import run_config
-                res["secondary"] = [run_config(name, dev, 10) for name in ("har", "logmel", "epic", "pcm", "resample", "patch", "patch16")]
+                res["secondary"] = [run_config(name, dev, 10) for name in ("har", "logmel", "epic", "pcm", "resample", "patch", "patch16", "tokens")]
             except Exception as exc:  # never let a secondary configuration take the headline line down
                 res["secondary"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
