@@ -252,6 +252,11 @@ typedef struct mmfe_patch_embed mmfe_patch_embed;
 int mmfe_patch_embed_create(int32_t height, int32_t width, int32_t patch, int32_t embed_dim, const float* weight, const float* bias,
                             int32_t in_dtype, int32_t compute_dtype, int32_t out_dtype, int device, mmfe_patch_embed** out_handle);
 int mmfe_patch_embed_destroy(mmfe_patch_embed* handle);
+/* New weights for an existing handle, read from DEVICE memory (the Conv2d parameters of a model in training, after an optimizer
+ * step: vanilla_single.py:75-80): weight_dev (embed_dim, 256) float32 contiguous, bias_dev embed_dim floats or NULL (zeros).  One
+ * small kernel on hip_stream re-packs and rounds them as mmfe_patch_embed_create does on the host: no allocation, no
+ * synchronisation; calls of mmfe_patch_embed_run issued later on the same stream use the new weights. */
+int mmfe_patch_embed_update(mmfe_patch_embed* handle, const float* weight_dev, const float* bias_dev, void* hip_stream);
 /* P and embed_dim of the tokens one image yields. */
 int mmfe_patch_embed_shape(const mmfe_patch_embed* handle, int64_t* n_patches, int64_t* embed_dim);
 /* x: device, n_batch images (elements of in_dtype) of height x width (unit column stride, row stride = width), image b starting

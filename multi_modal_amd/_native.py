@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "mmfe_abi_version", "mmfe_last_error", "mmfe_device_count", "mmfe_spec_out_shape",
     "mmfe_plan_create", "mmfe_plan_destroy", "mmfe_run", "mmfe_run_noalloc", "mmfe_run_slices", "mmfe_run_ragged", "mmfe_run_slices_ragged", "mmfe_feature_sums",
     "mmfe_plan_kernel",
-    "mmfe_patch_embed_create", "mmfe_patch_embed_destroy", "mmfe_patch_embed_shape", "mmfe_patch_embed_run",
+    "mmfe_patch_embed_create", "mmfe_patch_embed_destroy", "mmfe_patch_embed_shape", "mmfe_patch_embed_run", "mmfe_patch_embed_update",
 )
 
 
@@ -124,6 +124,8 @@ def bind_library(path: str):
     lib.mmfe_patch_embed_destroy.argtypes = [ctypes.c_void_p]
     lib.mmfe_patch_embed_shape.restype = ctypes.c_int
     lib.mmfe_patch_embed_shape.argtypes = [ctypes.c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]
+    lib.mmfe_patch_embed_update.restype = ctypes.c_int
+    lib.mmfe_patch_embed_update.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.mmfe_patch_embed_run.restype = ctypes.c_int
     lib.mmfe_patch_embed_run.argtypes = [ctypes.c_void_p, c_f_p, c_i64, c_i64, c_f_p, c_i64, ctypes.c_void_p]
     if lib.mmfe_abi_version() != ABI_VERSION:
@@ -276,6 +278,11 @@ class PatchEmbedHandle:
     def run_ptr(self, x_ptr: int, x_batch_stride: int, n_batch: int, out_ptr: int, out_batch_stride: int, stream: int = 0) -> None:
         check(self._lib.mmfe_patch_embed_run(self._handle, x_ptr, int(x_batch_stride), int(n_batch), out_ptr, int(out_batch_stride),
                                              ctypes.c_void_p(stream) if stream else None), "mmfe_patch_embed_run")
+
+    def update_ptr(self, weight_ptr: int, bias_ptr: int, stream: int = 0) -> None:
+        """New weights from device memory ((E, 256) float32 contiguous; bias_ptr 0 = no bias), re-packed by a kernel on `stream`."""
+        check(self._lib.mmfe_patch_embed_update(self._handle, weight_ptr, bias_ptr if bias_ptr else None,
+                                                ctypes.c_void_p(stream) if stream else None), "mmfe_patch_embed_update")
 
     def close(self) -> None:
         if getattr(self, "_handle", None):

@@ -283,6 +283,24 @@ __global__ void __launch_bounds__(kThreads) patch_embed_kernel(const PatchArgs p
     }
 }
 
+// Re-packs float32 weights that live on the device (the parameters of a model in training) into operand order, and rounds the
+// bias: one thread per weight.  Index arithmetic as in mmfe_patch_embed_create.
+__global__ void __launch_bounds__(256) patch_pack_kernel(const float* __restrict__ weight, const float* __restrict__ bias,
+                                                         unsigned short* __restrict__ pack, float* __restrict__ bias_out, int E, int NT, int bf, int paired) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < E * kK) {
+        const int j = i & 7, l = (i >> 3) & 63, s = (i >> 9) & 7, wt = i >> 12;      // [(wave * NT + t)][s][lane][j]
+        const int w = wt / NT, t = wt - w * NT, rho = l & 15, h = l >> 4;
+        const int col = w * 16 * NT + (paired ? 32 * (t >> 1) + 8 * (rho >> 2) + 4 * (t & 1) + (rho & 3) : 16 * t + rho);
+        const float v = weight[(size_t)col * kK + 64 * h + 8 * s + j];
+        pack[i] = bf ? bf16_bits(v) : f16_bits(v);
+    }
+    if (i < E) {
+        const float v = bias != nullptr ? bias[i] : 0.f;
+        bias_out[i] = bf ? __uint_as_float((unsigned)bf16_bits(v) << 16) : (float)static_cast<_Float16>(v);
+    }
+}
+
 unsigned short host_bf16(float v) {
     unsigned u;
     std::memcpy(&u, &v, 4);
@@ -385,6 +403,21 @@ int mmfe_patch_embed_create(int32_t height, int32_t width, int32_t patch, int32_
     if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     if (rc) { (void)hipFree(pe->d_wpack); (void)hipFree(pe->d_bias); delete pe; return rc; }
     *out_handle = reinterpret_cast<mmfe_patch_embed*>(pe);
+    return MMFE_OK;
+}
+
+int mmfe_patch_embed_update(mmfe_patch_embed* handle, const float* weight_dev, const float* bias_dev, void* hip_stream) {
+    PatchEmbed* pe = reinterpret_cast<PatchEmbed*>(handle);
+    if (pe == nullptr || weight_dev == nullptr) { set_error("patch_embed_update: NULL handle or weight"); return MMFE_EINVAL; }
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess || (prev != pe->device && hipSetDevice(pe->device) != hipSuccess)) { set_error("cannot make device %d current", pe->device); return MMFE_EHIP; }
+    const int n = pe->embed * kK;
+    const int paired = pe->out_dtype != MMFE_OUT_F32 && pe->nt % 2 == 0;
+    hipLaunchKernelGGL(patch_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), weight_dev, bias_dev,
+                       reinterpret_cast<unsigned short*>(pe->d_wpack), pe->d_bias, pe->embed, pe->nt, pe->compute == MMFE_OUT_BF16 ? 1 : 0, paired);
+    const hipError_t e = hipGetLastError();
+    if (prev >= 0 && prev != pe->device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) { set_error("patch_embed_update launch failed: %s", hipGetErrorString(e)); return MMFE_EHIP; }
     return MMFE_OK;
 }
 

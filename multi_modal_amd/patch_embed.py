@@ -107,3 +107,98 @@ class PatchEmbed:
         for h in self._handles.values():
             h.close()
         self._handles.clear()
+
+
+class _PatchEmbedFn(torch.autograd.Function):
+    """Forward on the matrix-pipe kernel; backward with torch's own matrix products (plain library GEMMs: the layer's gradients
+    are outside the front-end path, they only have to exist so that a model that trains this layer can keep it)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, layer):
+        ctx.layer = layer
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return layer._kernel(x)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, weight = ctx.saved_tensors
+        layer = ctx.layer
+        H, W = layer.img_size
+        Ph, Pw = H // PATCH, W // PATCH
+        B = x.shape[0]
+        cd = layer.compute_dtype
+        g = grad.reshape(B * Ph * Pw, -1).float()
+        gw = gb = gx = None
+        if ctx.needs_input_grad[1]:
+            # the patches the kernel multiplied: the image rounded to the products' type, (B, Ph, 16, Pw, 16) -> (B Ph Pw, 256)
+            img = x.reshape(B, H, W)[:, : Ph * PATCH, : Pw * PATCH].to(cd).float()
+            patches = img.reshape(B, Ph, PATCH, Pw, PATCH).permute(0, 1, 3, 2, 4).reshape(B * Ph * Pw, PATCH * PATCH)
+            gw = (g.t() @ patches).reshape(weight.shape).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(0)
+        if ctx.needs_input_grad[0]:
+            wr = weight.reshape(weight.shape[0], PATCH * PATCH).to(cd).float()
+            gp = (g @ wr).reshape(B, Ph, Pw, PATCH, PATCH).permute(0, 1, 3, 2, 4).reshape(B, Ph * PATCH, Pw * PATCH)
+            gx = torch.zeros(B, H, W, dtype=torch.float32, device=x.device)
+            gx[:, : Ph * PATCH, : Pw * PATCH] = gp
+            gx = gx.reshape(x.shape).to(x.dtype)
+        return gx, gw, gb, None
+
+
+class PatchEmbedLayer(torch.nn.Module):
+    """The reference's PatchEmbed module (classification/vggsound/models/vit_model.py:179-199) after AudioTransformer has
+    replaced its projection (vit_model.py:435-439): same attributes (`img_size`, `patch_size`, `num_patches`, `proj` = a
+    Conv2d(1, embed_dim, 16, stride 16) whose `weight` / `bias` are the parameters), so a state_dict of the reference's module
+    loads into it, and `forward(x)` = `self.proj(x).flatten(2).transpose(1, 2)` as @autocast() evaluates it.
+
+    The forward pass runs on the matrix-pipe kernel.  After an optimizer step has changed `proj.weight` / `proj.bias` (their
+    version counters move) the next forward re-packs them on the device (mmfe_patch_embed_update: one small kernel on the
+    current stream, nothing goes through the host).  Gradients of weight, bias and image come from torch's own products."""
+
+    def __init__(self, img_size=(384, 128), patch_size: int = 16, in_chans: int = 1, embed_dim: int = 768,
+                 compute_dtype: torch.dtype = torch.float16, out_dtype: torch.dtype = torch.float32):
+        super().__init__()
+        if patch_size != PATCH and tuple(patch_size if not isinstance(patch_size, int) else (patch_size,) * 2) != (PATCH, PATCH):
+            raise ValueError("the kernel is built for 16 x 16 patches")
+        if in_chans != 1:
+            raise ValueError("the audio projection has one input channel (vit_model.py:435)")
+        if isinstance(img_size, int):
+            img_size = (img_size, img_size)
+        self.img_size = (int(img_size[0]), int(img_size[1]))
+        self.patch_size = (PATCH, PATCH)
+        self.num_patches = (self.img_size[0] // PATCH) * (self.img_size[1] // PATCH)
+        self.compute_dtype, self.out_dtype = compute_dtype, out_dtype
+        self.proj = torch.nn.Conv2d(1, embed_dim, kernel_size=(PATCH, PATCH), stride=(PATCH, PATCH))
+        self._pe = None
+        self._seen = None
+
+    def _kernel(self, x: torch.Tensor) -> torch.Tensor:
+        w, b = self.proj.weight, self.proj.bias
+        if not w.is_cuda:
+            raise RuntimeError("PatchEmbedLayer runs on an MI355X: move the module to the GPU (there is no CPU fallback)")
+        key = (w.data_ptr(), w._version, None if b is None else b.data_ptr(), None if b is None else b._version, w.device.index)
+        if self._pe is None or self._pe.device != w.device.index:
+            self._pe = PatchEmbed(self.img_size, w.detach(), None if b is None else b.detach(), compute_dtype=self.compute_dtype,
+                                  out_dtype=self.out_dtype, device=w.device.index)
+            self._seen = key
+        elif key != self._seen:
+            wc = w.detach().reshape(w.shape[0], PATCH * PATCH).float().contiguous()
+            bc = None if b is None else b.detach().float().contiguous()
+            stream = torch.cuda.current_stream(w.device).cuda_stream
+            for h in self._pe._handles.values():
+                h.update_ptr(wc.data_ptr(), 0 if bc is None else bc.data_ptr(), stream)
+            self._host_stale = True
+            self._seen = key
+        in_dtype = x.dtype if (x.dtype == self.compute_dtype and self.img_size[1] % 8 == 0) else torch.float32
+        if in_dtype not in self._pe._handles and getattr(self, "_host_stale", False):
+            # a first call with this image dtype after the weights have moved: its handle is packed from the live parameters
+            self._pe._w = w.detach().reshape(w.shape[0], PATCH * PATCH).float().cpu().contiguous().numpy()
+            self._pe._b = None if b is None else b.detach().float().cpu().numpy()
+            self._host_stale = False
+        return self._pe(x)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if torch.is_grad_enabled() and (x.requires_grad or self.proj.weight.requires_grad):
+            return _PatchEmbedFn.apply(x, self.proj.weight, self.proj.bias, self)
+        return self._kernel(x)

@@ -259,3 +259,43 @@ def test_epic_spectrogram_to_tokens_pipeline(mm, O):
     assert tokens.shape == (3, 256, 768)
     assert ((tokens.cpu().double() - same).abs() <= 2e-5 * scale + 1e-6).all()
     assert ((tokens.cpu().double() - ref).abs() <= 2e-3 * scale + 1e-5).all()
+
+
+def test_patch_embed_layer_trains_like_the_reference_module(mm, O, golden_dir):
+    """PatchEmbedLayer is the reference's PatchEmbed module with the audio projection: its state_dict keys are `proj.weight` /
+    `proj.bias` (what a checkpoint of the reference holds for this layer), forward equals the autocast convolution, the gradients
+    of weight, bias and image equal those of torch's convolution on the rounded operands, and after an optimizer step the next
+    forward uses the new weights (re-packed on the device) for float32 and for 16-bit images."""
+    from multi_modal_amd.patch_embed import PatchEmbedLayer
+    torch.manual_seed(0)
+    layer = PatchEmbedLayer((384, 128), embed_dim=768, compute_dtype=torch.float16).cuda()
+    assert sorted(layer.state_dict().keys()) == ["proj.bias", "proj.weight"] and layer.num_patches == 192
+    ref = torch.nn.Conv2d(1, 768, 16, 16)
+    layer.load_state_dict({"proj.weight": ref.weight.detach().clone(), "proj.bias": ref.bias.detach().clone()})
+    x = (torch.randn(3, 1, 384, 128) * 1.2).cuda().requires_grad_(True)
+    opt = torch.optim.SGD(layer.parameters(), lr=0.05)
+    for step in range(3):
+        opt.zero_grad()
+        x.grad = None
+        y = layer(x)
+        loss = (y * torch.linspace(-1, 1, 768, device="cuda")).sum() / 100.0 + (y ** 2).mean()
+        loss.backward()
+        # the same step on the CPU: convolution of the operands as rounded by autocast, in float64
+        w64 = layer.proj.weight.detach().cpu().half().double().requires_grad_(True)
+        b64 = layer.proj.bias.detach().cpu().half().double().requires_grad_(True)
+        x64 = x.detach().cpu().half().double().requires_grad_(True)
+        y64 = torch.nn.functional.conv2d(x64, w64, b64, stride=16).flatten(2).transpose(1, 2)
+        loss64 = (y64 * torch.linspace(-1, 1, 768, dtype=torch.float64)).sum() / 100.0 + (y64 ** 2).mean()
+        loss64.backward()
+        assert (y.detach().cpu().double() - y64.detach()).abs().max() <= 2e-4
+        for got, want in ((layer.proj.weight.grad, w64.grad), (layer.proj.bias.grad, b64.grad), (x.grad, x64.grad)):
+            err = (got.cpu().double() - want).abs().max()
+            assert err <= 2e-4 * want.abs().max() + 1e-7, (step, err, want.abs().max())
+        opt.step()                                   # the parameters move: the next forward must see them
+    with torch.no_grad():
+        y32 = layer(x.detach())
+        y16 = layer(x.detach().half())               # first call with a 16-bit image, after the weights have moved
+        want = O.patch_embed(x.detach().cpu(), layer.proj.weight.detach().cpu(), layer.proj.bias.detach().cpu(), compute_dtype=torch.float16,
+                             out_dtype=torch.float64)
+    assert (y32.cpu().double() - want).abs().max() <= 2e-4
+    assert torch.equal(y16, y32)
