@@ -296,6 +296,23 @@ def main():
                                "ms_per_step_with_allgather": round(1e3 * el / k, 3), "allgather_ms": round(1e3 * el_g / k, 3),
                                "gathered_GB_per_s_per_rank": round(recv * k / el_g / 1e9, 1),
                                "frac_of_xgmi_7x153GBs": round(recv * k / el_g / 1e9 / XGMI_PEAK_GBS, 4)}
+            # the same shard transformed and exchanged in 4 pieces, each piece's exchange under the next piece's transform
+            try:
+                fn = (lambda xs: mm.logmel.log_mel_spectrogram(xs)) if args.config == "logmel" else (lambda xs: mm.preprocessing_audio_batch(xs))
+                for _ in range(2):
+                    partition._gather_chunked(fn, x, n_items, rank, world, 4, None)
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(k):
+                    partition._gather_chunked(fn, x, n_items, rank, world, 4, None)
+                fence()
+                t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+                modes["direct_4_pieces_overlapped"] = {cfg["unit"].replace("/s", "_per_s_with_allgather"): round(world * B * k / el, 1),
+                                                       "ms_per_step_with_allgather": round(1e3 * el / k, 3)}
+            except Exception as exc:
+                modes["direct_4_pieces_overlapped"] = {"error": repr(exc)}
             picked = partition.pick_gather_mode("auto", world, True, True)
             gather = dict(modes[picked])
             gather.update({"received_bytes_per_rank": recv, "steps": k, "auto_picks": picked, "modes": modes,

@@ -118,13 +118,56 @@ def all_gather_features(local: torch.Tensor, n_items: int, group=None, out: Opti
     return _gather_collective(local, n_items, per, world, group, out)
 
 
+def _gather_chunked(fn, local_in: torch.Tensor, n_items: int, rank: int, world: int, chunks: int, group) -> torch.Tensor:
+    """Compute and exchange in `chunks` pieces: while piece c of every shard travels (asynchronous point-to-point operations into the
+    final slots of the output, on the communication library's own stream), the transform of piece c + 1 runs.  Every rank cuts every
+    shard at the same places (piece c of a shard of s items is [c * ceil(s / chunks), ...)), so both sides of every transfer know its
+    size without a handshake.  The exchange hides at most the compute, which is the smaller part."""
+    lo, hi = shard_range(n_items, rank, world)
+
+    def piece(r: int, c: int) -> Tuple[int, int]:
+        rlo, rhi = shard_range(n_items, r, world)
+        step = -(-(rhi - rlo) // chunks) if rhi > rlo else 0
+        a = min(rlo + c * step, rhi)
+        return a, min(a + step, rhi)
+
+    out = None
+    pending = []
+    for c in range(chunks):
+        a, b = piece(rank, c)
+        y = fn(local_in[a - lo:b - lo]) if b > a else None
+        if out is None:
+            probe = y if y is not None else fn(local_in[:0])
+            out = probe.new_empty((n_items,) + tuple(probe.shape[1:]))
+        if y is not None:
+            out[a:b].copy_(y)
+        ops = []
+        for step in range(1, world):
+            dst, src = (rank + step) % world, (rank - step) % world
+            if b > a:
+                ops.append(dist.P2POp(dist.isend, out[a:b], dst if group is None else dist.get_global_rank(group, dst), group))
+            sa, sb = piece(src, c)
+            if sb > sa:
+                ops.append(dist.P2POp(dist.irecv, out[sa:sb], src if group is None else dist.get_global_rank(group, src), group))
+        if ops:
+            pending += dist.batch_isend_irecv(ops)
+    for r in pending:
+        r.wait()
+    return out
+
+
 def sharded_apply(fn: Callable[[torch.Tensor], torch.Tensor], batch: torch.Tensor, gather: bool = True, group=None,
-                  mode: str = "auto") -> torch.Tensor:
+                  mode: str = "auto", chunks: int = 1) -> torch.Tensor:
     """Run `fn` (a batched front-end such as preprocessing_audio_batch) on this rank's contiguous shard of
-    `batch` and, if `gather`, return the whole feature tensor on every rank (`mode`: see all_gather_features)."""
+    `batch` and, if `gather`, return the whole feature tensor on every rank (`mode`: see all_gather_features).
+    chunks > 1: the shard is transformed and exchanged in that many pieces, the exchange of one piece under the transform of the
+    next (point-to-point form; `mode` is ignored)."""
     n = batch.shape[0]
     if not dist.is_initialized():
         return fn(batch)
-    lo, hi = shard_range(n, dist.get_rank(group), dist.get_world_size(group))
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi = shard_range(n, rank, world)
+    if gather and chunks > 1 and world > 1:
+        return _gather_chunked(fn, batch[lo:hi], n, rank, world, int(chunks), group)
     local = fn(batch[lo:hi])
     return all_gather_features(local, n, group, mode=mode) if gather else local

@@ -137,3 +137,4 @@ def test_bench_configs_under_one_rank_group(tmp_path):
         for mode in ("collective", "direct"):
             assert res["allgather"]["modes"][mode]["allgather_ms"] > 0, res["allgather"]
         assert res["allgather"]["auto_picks"] in ("collective", "direct")
+        assert res["allgather"]["modes"]["direct_4_pieces_overlapped"].get("ms_per_step_with_allgather", 0) > 0, res["allgather"]

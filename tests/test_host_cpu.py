@@ -247,6 +247,8 @@ for n in (7, 8, 1, 12, 2):
     for mode in ("collective", "direct"):
         assert torch.equal(sharded_apply(fn, batch, mode=mode), fn(batch))
     assert sharded_apply(fn, batch, gather=False).shape[0] == hi - lo
+    for chunks in (2, 3, 5):           # transformed and exchanged piece by piece: the same tensor
+        assert torch.equal(sharded_apply(fn, batch, chunks=chunks), fn(batch)), (n, rank, chunks)
 assert pick_gather_mode("auto", 8, True, True) == "direct" and pick_gather_mode("auto", 2, True, True) == "collective"
 assert pick_gather_mode("auto", 2, False, False) == "direct" and pick_gather_mode("auto", 3, True, False) == "collective"
 dist.barrier()
