@@ -347,6 +347,9 @@ def main():
                          "kernel_min_ms": round(kernel_ms[0], 4), "kernel_median_ms": round(kernel_ms[len(kernel_ms) // 2], 4),
                          "algorithmic_bytes_per_unit": cfg["bytes_per_unit"], "units_per_launch": B},
         }
+        if args.config in ("vgg4096", "vgg200k"):
+            res["roofline"]["bound_note"] = ("priced against HBM as the metric asks; measured, the kernel takes the same shader cycles with and without its memory "
+                                             "traffic and is held at about 1.98 GHz by the power limit (profiles/r03_fbank512_clock.txt)")
         if traffic is not None:
             res["roofline"]["traffic_source"] = TRAFFIC_SOURCE
         if traffic_note:
